@@ -1,0 +1,182 @@
+/* sbgm_hip.h — C ABI of libsbgm_hip.so: the MI355X (gfx950) implementation of the SBGM_DANRA score-UNet forward
+ * and reverse-SDE sampling hot path.
+ *
+ * Boundary: this library sits between the reference's Python layer L1 (sbgm/score_unet.py, sbgm/score_sampling.py)
+ * and what used to be torch.nn ops.  Plain pointers and sizes only; every pointer is a DEVICE pointer unless said
+ * otherwise; every call enqueues on `stream` (a hipStream_t passed as void*) and returns without synchronising.
+ * Return value: 0 = ok, non-zero = error (text via sbgm_last_error()).  The Python mirror raises RuntimeError.
+ *
+ * Tensor conventions at the boundary are the reference's: NCHW contiguous fp32, t float [B], y int64 [B] with
+ * 0 = null class (reference score_unet.py:224-226).  Internally everything is NHWC; the *_nhwc per-op entry
+ * points below expose that layout for unit parity tests.
+ */
+#ifndef SBGM_HIP_H
+#define SBGM_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sbgm_model sbgm_model;
+
+const char* sbgm_last_error(void);
+int sbgm_abi_version(void);
+
+enum { SBGM_NONE = 0, SBGM_RELU = 1, SBGM_SILU = 2, SBGM_GELU = 3 };   /* activation codes */
+enum { SBGM_NORM_INSTANCE = 0, SBGM_NORM_GROUP = 1 };
+enum { SBGM_SAMPLER_EM = 0, SBGM_SAMPLER_PC = 1 };
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Model handle.  Replaces: training_utils.get_model -> Encoder/Decoder/ScoreNet construction
+ * (reference training_utils.py:645-666) + ScoreNet.forward (score_unet.py:829-879).
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct sbgm_model_config {
+    int n_lsm_channels;      /* 0 or 2: lsm_cond value||mask          (cat order: x, lsm, topo, cond_img; :273-291) */
+    int n_topo_channels;     /* 0 or 2 */
+    int n_cond_channels;     /* LR condition channels */
+    int time_embedding;      /* cfg.sampler.time_embedding */
+    int block_layers[4];     /* cfg.sampler.block_layers */
+    int n_heads;             /* cfg.sampler.num_heads */
+    int num_classes;         /* 0 = no label embedding, else n_seasons (table has num_classes+1 rows) */
+    int last_fmap_channels;  /* cfg.sampler.last_fmap_channels (512) */
+    int decoder_norm;        /* SBGM_NORM_* (cfg.model.decoder_norm) */
+    int gn_groups;           /* cfg.model.decoder_gn_groups */
+    int decoder_activation;  /* SBGM_RELU / SBGM_SILU / SBGM_GELU (cfg.model.decoder_activation) */
+    float sigma;             /* VE-SDE sigma (25.0, score_unet.py:932) */
+} sbgm_model_config;
+
+int sbgm_model_create(const sbgm_model_config* cfg, sbgm_model** out);
+void sbgm_model_destroy(sbgm_model* m);
+
+/* Number of state_dict entries the model expects, and the i-th entry's name / element count (host strings). */
+int sbgm_model_num_params(const sbgm_model* m);
+const char* sbgm_model_param_name(const sbgm_model* m, int i);
+int64_t sbgm_model_param_numel(const sbgm_model* m, int i);
+
+/* Upload one state_dict tensor (device pointer, reference layout: OIHW convs, [out,in] linears, packed
+ * mha.in_proj_weight [3C,C]).  The engine repacks into its own NHWC / K-major storage.  Replaces
+ * nn.Module.load_state_dict for the path.  `num_batches_tracked` entries are accepted and ignored. */
+int sbgm_model_set_param(sbgm_model* m, const char* name, const void* data, int64_t numel, void* stream);
+/* Copy an engine-held tensor back in reference layout (used for BatchNorm running statistics after train-mode
+ * forwards).  Only vector-shaped entries are supported. */
+int sbgm_model_get_param(sbgm_model* m, const char* name, float* dst, int64_t numel, void* stream);
+/* 0 when every expected entry has been uploaded; otherwise an error naming the first missing one. */
+int sbgm_model_check_complete(const sbgm_model* m);
+
+/* score = ScoreNet(x, t, y, cond_img, lsm_cond, topo_cond); out is NCHW [B,1,H,W].  Optional inputs may be NULL
+ * when the model was configured with 0 channels for them.  bn_train != 0 uses batch statistics in the encoder's
+ * BatchNorm layers and updates the engine-held running statistics (nn.Module.train() semantics).
+ * fmaps (optional, may be NULL): 5 device pointers that receive the encoder feature maps in NHWC. */
+int sbgm_model_forward(sbgm_model* m, const float* x, const float* t, const int64_t* y, const float* cond_img,
+                       const float* lsm_cond, const float* topo_cond, float* out, float* const* fmaps, int B, int H,
+                       int W, int bn_train, void* stream);
+
+/* Whole reverse-SDE sampling loop on the device.  Replaces Euler_Maruyama_sampler / pc_sampler
+ * (reference score_sampling.py:63-127, :136-230) when classifier-free guidance is off.
+ *   noise: NULL -> in-kernel Philox draws keyed by `seed`; else [n_draws][B][1][H][W] host-ordered N(0,1) draws
+ *          consumed as the reference consumes torch.randn: init, then per step (corrector,) predictor.
+ *   out:   x_mean after the last step, NCHW [B,1,H,W].
+ *   use_graph: capture one SDE step into a hipGraph and replay it (ignored when noise != NULL). */
+typedef struct sbgm_sampler_args {
+    int kind;                /* SBGM_SAMPLER_* */
+    int B, H, W;
+    int num_steps;
+    float eps;               /* smallest time (1e-3) */
+    float snr;               /* PC only (0.16) */
+    uint64_t seed;
+    int use_graph;
+    int bn_train;            /* literal reference launch_generation behaviour (generation.py:47) when != 0 */
+    const int64_t* y;
+    const float* cond_img;
+    const float* lsm_cond;
+    const float* topo_cond;
+    const float* noise;
+    float* out;
+} sbgm_sampler_args;
+int sbgm_sampler_run(sbgm_model* m, const sbgm_sampler_args* a, void* stream);
+
+/* Conv autotuning: time the tile / split-K candidates of every convolution of the (B,H,W) plan once and keep the
+ * fastest.  Synchronises the stream.  Optional; without it a static heuristic is used. */
+int sbgm_model_autotune(sbgm_model* m, int B, int H, int W, void* stream);
+/* Device time of the last N forwards is not tracked here; bench.py brackets calls with HIP events it gets from: */
+int sbgm_event_create(void** ev);
+int sbgm_event_record(void* ev, void* stream);
+int sbgm_event_elapsed_ms(void* start, void* stop, float* ms);   /* synchronises on `stop` */
+int sbgm_event_destroy(void* ev);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Per-op entry points (NHWC fp32).  Each names the torch op instance it replaces.
+ * ---------------------------------------------------------------------------------------------------------- */
+/* torch.cat + .contiguous(NHWC): up to 4 NCHW sources -> [B,H,W,Cpad] (zero padded).  score_unet.py:273-291 */
+int sbgm_pack_input(const float* const* srcs, const int* src_channels, int n_src, float* dst_nhwc, int B, int H,
+                    int W, int c_pad, void* stream);
+int sbgm_nchw_to_nhwc(const float* src, float* dst, int B, int H, int W, int C, void* stream);
+int sbgm_nhwc_to_nchw(const float* src, float* dst, int B, int H, int W, int C, void* stream);
+
+/* nn.Conv2d / nn.Linear weight repack: OIHW -> [k_step][Cout][16].  Returns packed float count via
+ * sbgm_conv_packed_numel.  c_pad: padded input channels (4, 8 or a multiple of 16). */
+int64_t sbgm_conv_packed_numel(int Cout, int KH, int KW, int c_pad);
+int sbgm_conv_pack_weight(const float* w_oihw, float* packed, int Cout, int Cin, int KH, int KW, int c_pad, void* stream);
+/* nn.Conv2d (+ folded BatchNorm scale/bias, + time bias, + residual, + ReLU) on the fp32 MFMA implicit-GEMM
+ * kernel.  score_unet.py:206-219, torchvision BasicBlock convs, :468, :489; nn.Linear as 1x1 (:127-134).
+ * tile_co/tile_px/splits = 0 -> heuristic.  ws: split-K scratch (>= splits*M*Cout floats) or NULL if splits<=1. */
+typedef struct sbgm_conv_args {
+    const float* x;          /* [B,H,W,c_pad] */
+    const float* w_packed;
+    float* out;              /* [B,OH,OW,Cout] */
+    const float* scale;      /* [Cout] or NULL */
+    const float* bias;       /* [Cout] or NULL */
+    const float* tbias;      /* [B,Cout] or NULL */
+    const float* residual;   /* [B,OH,OW,Cout] or NULL */
+    int B, H, W, c_pad, Cout;
+    int KH, KW, stride, pad;
+    int relu;
+    int tbias_after_act;
+    int tile_co, tile_px, splits;
+    float* ws;
+    int64_t ws_floats;
+} sbgm_conv_args;
+int sbgm_conv2d_fwd(const sbgm_conv_args* a, void* stream);
+
+/* nn.Upsample(scale_factor=2, mode="bilinear", align_corners=False).  score_unet.py:467 */
+int sbgm_upsample2x_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream);
+/* nn.GroupNorm / nn.InstanceNorm2d (+ skip add, + time bias, + activation).  score_unet.py:480-483, :585-615.
+ * gamma/beta NULL = no affine (InstanceNorm2d default).  stats_ws: >= 24*B*G bytes. */
+int sbgm_groupnorm_fwd(const float* x, float* y, const float* gamma, const float* beta, const float* skip,
+                       const float* tbias, int act, int B, int HW, int C, int G, float eps, void* stats_ws, void* stream);
+/* nn.LayerNorm(C).  score_unet.py:128-129 */
+int sbgm_layernorm_fwd(const float* x, float* y, const float* gamma, const float* beta, int M, int C, float eps, void* stream);
+/* nn.BatchNorm2d in training mode (+ residual, ReLU, time bias).  stats_ws: >= 24*C bytes. */
+int sbgm_batchnorm_train_fwd(const float* x, float* y, const float* gamma, const float* beta, float* running_mean,
+                             float* running_var, const float* residual, const float* tbias_after, int relu, int B, int HW,
+                             int C, float eps, float momentum, void* stats_ws, void* stream);
+/* Core of nn.MultiheadAttention between in_proj and out_proj: qkv [B,S,3C] -> [B,S,C].  score_unet.py:142 */
+int sbgm_mha_core_fwd(const float* qkv, float* out, int B, int S, int C, int heads, void* stream);
+/* SinusoidalEmbedding (+ label embedding) -> SiLU -> Linear, for one projection.  score_unet.py:41-45, :377-381 */
+int sbgm_time_proj_fwd(const float* t, const int64_t* y, const float* label_emb, const float* freqs, const float* weight,
+                       const float* bias, float* out, float* emb_ws, int B, int D, int ch, void* stream);
+/* final_layer.conv (3x3, C->1) + division by marginal_prob_std(t).  score_unet.py:489, :876-877.
+ * w_tap_c from sbgm_cout1_pack_weight; t NULL = no division. */
+int sbgm_cout1_pack_weight(const float* w_oihw, float* w_tap_c, int C, void* stream);
+int sbgm_conv3x3_cout1_fwd(const float* x, const float* w_tap_c, const float* bias, const float* t, float sigma, float* out,
+                           int B, int H, int W, int C, void* stream);
+/* Elementwise activation in place (GELU between the attention FF linears, score_unet.py:132). */
+int sbgm_act_inplace(float* x, int64_t n, int act, void* stream);
+
+/* Sampler updates with explicit scalars (the fused loop above uses a device-side table instead).
+ * z NULL -> Philox draw keyed by (seed, draw_index).
+ *   em:       x_mean = x + (g2*score)*dt ; x = x_mean + noise_coef*z            score_sampling.py:124-125, :224-227
+ *   langevin: eps = 2*(snr_noise_norm / mean_b||score_b||)^2 ; x += eps*score + sqrt(2 eps)*z      :200-204
+ *   cfg:      out = (1+w)*s_cond - w*s_uncond                                                        :55      */
+int sbgm_em_step(float* x, float* x_mean, const float* score, const float* z, float g2, float dt, float noise_coef,
+                 uint64_t seed, uint64_t draw_index, int64_t n, void* stream);
+int sbgm_langevin_step(float* x, const float* score, const float* z, float snr_noise_norm, void* sumsq_ws /* >= 8*B B */,
+                       uint64_t seed, uint64_t draw_index, int B, int64_t per_sample, void* stream);
+int sbgm_cfg_combine(float* out, const float* s_cond, const float* s_uncond, float scale, int64_t n, void* stream);
+int sbgm_randn_scaled(float* x, float scale, uint64_t seed, uint64_t draw_index, int64_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

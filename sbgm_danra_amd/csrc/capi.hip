@@ -1,0 +1,100 @@
+// Per-op C-ABI entry points declared in include/sbgm_hip.h (the model / sampler entry points live in engine.hip).
+#include "../../include/sbgm_hip.h"
+#include "common.h"
+#include "kernels.h"
+
+#define ST ((hipStream_t)stream)
+
+extern "C" {
+
+int sbgm_pack_input(const float* const* srcs, const int* src_channels, int n_src, float* dst_nhwc, int B, int H, int W,
+                    int c_pad, void* stream) {
+    SBGM_CHECK(n_src >= 1 && n_src <= 4, "pack_input: n_src=%d (1..4)", n_src);
+    PackSrc s{};
+    s.n = n_src;
+    for (int i = 0; i < n_src; ++i) { s.ptr[i] = srcs[i]; s.ch[i] = src_channels[i]; }
+    return sbgm_launch_pack_input(s, dst_nhwc, B, H, W, c_pad, ST);
+}
+int sbgm_nchw_to_nhwc(const float* src, float* dst, int B, int H, int W, int C, void* stream) {
+    return sbgm_launch_nchw_to_nhwc(src, dst, B, H, W, C, ST);
+}
+int sbgm_nhwc_to_nchw(const float* src, float* dst, int B, int H, int W, int C, void* stream) {
+    return sbgm_launch_nhwc_to_nchw(src, dst, B, H, W, C, ST);
+}
+
+int64_t sbgm_conv_packed_numel(int Cout, int KH, int KW, int c_pad) {
+    return (int64_t)sbgm_conv_nsteps(KH, KW, c_pad) * Cout * 16;
+}
+int sbgm_conv_pack_weight(const float* w_oihw, float* packed, int Cout, int Cin, int KH, int KW, int c_pad, void* stream) {
+    return sbgm_launch_pack_conv_weight(w_oihw, packed, Cout, Cin, KH, KW, c_pad, ST);
+}
+
+int sbgm_conv2d_fwd(const sbgm_conv_args* a, void* stream) {
+    SBGM_CHECK(a && a->x && a->w_packed && a->out, "conv2d: null tensor");
+    ConvParams p{};
+    p.x = a->x; p.wp = a->w_packed; p.out = a->out; p.scale = a->scale; p.bias = a->bias; p.tbias = a->tbias;
+    p.res = a->residual; p.B = a->B; p.H = a->H; p.W = a->W; p.Cs = a->c_pad; p.Cout = a->Cout;
+    p.act = a->relu ? SBGM_ACT_RELU : SBGM_ACT_NONE;
+    p.tbias_after_act = a->tbias_after_act;
+    ConvTile t{a->tile_co ? a->tile_co : (a->Cout % 64 == 0 ? 4 : 2), a->tile_px ? a->tile_px : 2, a->splits ? a->splits : 1};
+    SBGM_CHECK(a->Cout % 32 == 0, "conv2d: Cout=%d must be a multiple of 32", a->Cout);
+    if (t.splits > 1) {
+        const int OH = (a->H + 2 * a->pad - a->KH) / a->stride + 1, OW = (a->W + 2 * a->pad - a->KW) / a->stride + 1;
+        SBGM_CHECK(a->ws && a->ws_floats >= (int64_t)t.splits * a->B * OH * OW * a->Cout, "conv2d: split-K workspace too small");
+    }
+    return sbgm_launch_conv(ConvGeom{a->KH, a->KW, a->stride, a->pad}, p, t, a->ws, ST);
+}
+
+int sbgm_upsample2x_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream) {
+    return sbgm_launch_upsample2x(x, y, B, H, W, C, ST);
+}
+int sbgm_groupnorm_fwd(const float* x, float* y, const float* gamma, const float* beta, const float* skip, const float* tbias,
+                       int act, int B, int HW, int C, int G, float eps, void* stats_ws, void* stream) {
+    return sbgm_launch_groupnorm(x, y, gamma, beta, skip, tbias, act, B, HW, C, G, eps, (double*)stats_ws, ST);
+}
+int sbgm_layernorm_fwd(const float* x, float* y, const float* gamma, const float* beta, int M, int C, float eps, void* stream) {
+    return sbgm_launch_layernorm(x, y, gamma, beta, M, C, eps, ST);
+}
+int sbgm_batchnorm_train_fwd(const float* x, float* y, const float* gamma, const float* beta, float* running_mean,
+                             float* running_var, const float* residual, const float* tbias_after, int relu, int B, int HW,
+                             int C, float eps, float momentum, void* stats_ws, void* stream) {
+    return sbgm_launch_batchnorm_train(x, y, gamma, beta, running_mean, running_var, residual, tbias_after, relu, B, HW, C, eps,
+                                       momentum, (double*)stats_ws, ST);
+}
+int sbgm_mha_core_fwd(const float* qkv, float* out, int B, int S, int C, int heads, void* stream) {
+    return sbgm_launch_mha_core(qkv, out, B, S, C, heads, ST);
+}
+int sbgm_time_proj_fwd(const float* t, const int64_t* y, const float* label_emb, const float* freqs, const float* weight,
+                       const float* bias, float* out, float* emb_ws, int B, int D, int ch, void* stream) {
+    TimeEmbedArgs a{};
+    a.t = t; a.y = y; a.label_emb = label_emb; a.freqs[0] = freqs; a.n_emb = 1; a.n_proj = 1;
+    a.proj[0] = TimeProj{weight, bias, out, ch, 0};
+    a.emb_ws = emb_ws; a.B = B; a.D = D;
+    return sbgm_launch_time_embed(a, ST);
+}
+int sbgm_cout1_pack_weight(const float* w_oihw, float* w_tap_c, int C, void* stream) {
+    return sbgm_launch_pack_cout1_weight(w_oihw, w_tap_c, C, ST);
+}
+int sbgm_conv3x3_cout1_fwd(const float* x, const float* w_tap_c, const float* bias, const float* t, float sigma, float* out,
+                           int B, int H, int W, int C, void* stream) {
+    return sbgm_launch_conv3x3_cout1(x, w_tap_c, bias, t, sigma, out, B, H, W, C, ST);
+}
+int sbgm_act_inplace(float* x, int64_t n, int act, void* stream) { return sbgm_launch_act(x, (size_t)n, act, ST); }
+
+int sbgm_em_step(float* x, float* x_mean, const float* score, const float* z, float g2, float dt, float noise_coef,
+                 uint64_t seed, uint64_t draw_index, int64_t n, void* stream) {
+    const StepScalars sc{0.f, g2, dt, noise_coef, 0.f};
+    return sbgm_launch_em_update(x, x_mean, score, z, nullptr, nullptr, &sc, draw_index, nullptr, seed, 1, (size_t)n, 1, ST);
+}
+int sbgm_langevin_step(float* x, const float* score, const float* z, float snr_noise_norm, void* sumsq_ws, uint64_t seed,
+                       uint64_t draw_index, int B, int64_t per_sample, void* stream) {
+    return sbgm_launch_langevin(x, score, z, snr_noise_norm, (double*)sumsq_ws, nullptr, draw_index, seed, B, (size_t)per_sample, ST);
+}
+int sbgm_cfg_combine(float* out, const float* s_cond, const float* s_uncond, float scale, int64_t n, void* stream) {
+    return sbgm_launch_cfg_combine(out, s_cond, s_uncond, scale, (size_t)n, ST);
+}
+int sbgm_randn_scaled(float* x, float scale, uint64_t seed, uint64_t draw_index, int64_t n, void* stream) {
+    return sbgm_launch_init_noise(x, scale, nullptr, seed, nullptr, draw_index, (size_t)n, ST);
+}
+
+}  // extern "C"

@@ -1,0 +1,312 @@
+// fp32 implicit-GEMM convolution on the CDNA4 matrix pipe (v_mfma_f32_16x16x4_f32: exact fp32 FMA chain,
+// same peak as the fp32 vector ALU), NHWC activations, wave-level tiles, no LDS and no barriers.
+//
+// Replaces every nn.Conv2d / nn.Linear instance on the reference hot path
+// (reference sbgm/score_unet.py:206-219 stem convs, torchvision BasicBlock convs used at :188,
+//  :468/:489 decoder convs, :127-134 attention projections / FF).
+//
+//   D[co][px] = sum_{tap, c}  Wp[step(tap,c/16)][co][c%16] * X[b, oy*S-PAD+kh, ox*S-PAD+kw, c]
+//
+// GEMM roles: A operand = packed weights (rows = output channels), B operand = gathered input pixels
+// (columns = output pixels), so each lane ends up owning 4 consecutive output channels of one pixel and
+// the epilogue stores one float4 per 16x16 fragment straight into NHWC.
+//
+// One wave computes an (16*FCO) x (16*FPX) output tile.  Per K-step (16 input channels of one filter tap)
+// a lane issues FCO + FPX 16-byte buffer loads (hardware bounds check supplies the zero padding) and
+// 4*FCO*FPX MFMAs; the next step's operands are prefetched into a second register set.  Tiles are mapped to
+// workgroups so that an XCD owns a contiguous range of (co-tile, px-tile) pairs (weights stay in its L2).
+// Small-M layers are filled with split-K over gridDim.y followed by splitk_reduce_epilogue.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+template <int FCO, int FPX>
+struct Frags {
+    f32x4 a[FCO];
+    f32x4 b[FPX];
+};
+
+struct PixLane {      // per-lane decode of the output pixel this lane gathers for / stores to
+    int base;         // b * H * W  (input pixel index of (b,0,0)); negative => lane inactive
+    int y0, x0;       // oy*S - PAD, ox*S - PAD
+};
+
+template <int KH, int KW, int S, int PAD, int FCO, int FPX, int CMODE>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r16 = lane & 15;     // row (co) for the A fragment, column (pixel) for the B fragment
+    const int kq = lane >> 4;      // which 4-channel quad of the 16-deep K step this lane supplies
+
+    // ---- workgroup -> tile range, XCD-contiguous (blocks b, b+8, ... share an XCD) ---------------
+    const int nb = gridDim.x, bid = blockIdx.x;
+    const int q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
+    const int lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const int tile = lb * 4 + wave;
+    if (tile >= p.n_px_tiles * p.n_co_tiles) return;
+    const int co_tile = tile / p.n_px_tiles;
+    const int px_tile = tile - co_tile * p.n_px_tiles;
+    const int co0 = co_tile * (16 * FCO);
+    const int m0 = px_tile * (16 * FPX);
+
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
+    const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.wp, p.w_bytes);
+
+    // ---- per-lane pixel decode -------------------------------------------------------------------
+    PixLane pl[FPX];
+    const int ohw = p.OH * p.OW;
+#pragma unroll
+    for (int f = 0; f < FPX; ++f) {
+        const int m = m0 + 16 * f + r16;
+        if (m < p.M) {
+            const int b = m / ohw;
+            const int rr = m - b * ohw;
+            const int oy = rr / p.OW;
+            const int ox = rr - oy * p.OW;
+            pl[f].base = b * p.H * p.W;
+            pl[f].y0 = oy * S - PAD;
+            pl[f].x0 = ox * S - PAD;
+        } else {
+            pl[f].base = 0;
+            pl[f].y0 = -(1 << 28);
+            pl[f].x0 = 0;
+        }
+    }
+
+    // ---- K range of this split ---------------------------------------------------------------------
+    const int s_begin = blockIdx.y * p.steps_per_split;
+    const int s_end = min(p.nsteps, s_begin + p.steps_per_split);
+
+    const uint32_t w_lane_off = (uint32_t)((co0 + r16) * 16 + kq * 4) * 4u;
+    const uint32_t w_step_stride = (uint32_t)p.Cout * 64u;   // bytes per K step: Cout rows x 16 floats
+
+    // running K-step state (scalar registers): step -> (kh, kw0, cb); advanced once per load
+    int st_s, st_kh, st_kw, st_cb;
+    auto seek = [&](int s) {
+        st_s = s;
+        if (CMODE == 0) {
+            const int tap = s / p.cb_per_tap;
+            st_cb = s - tap * p.cb_per_tap;
+            st_kh = tap / KW;
+            st_kw = tap - st_kh * KW;
+        } else {
+            constexpr int SPR = KW / (16 / (CMODE ? CMODE : 16));   // steps per filter row
+            st_kh = s / SPR;
+            st_kw = (s - st_kh * SPR) * (16 / (CMODE ? CMODE : 16));
+            st_cb = 0;
+        }
+    };
+    auto load_next = [&](Frags<FCO, FPX>& fr) {   // loads step st_s, then advances the state
+        int kw_lane, coff;
+        if (CMODE == 0) { kw_lane = st_kw; coff = st_cb * 16 + kq * 4; }
+        else if (CMODE == 4) { kw_lane = st_kw + kq; coff = 0; }
+        else { kw_lane = st_kw + (kq >> 1); coff = (kq & 1) * 4; }
+        const uint32_t wo = (uint32_t)st_s * w_step_stride + w_lane_off;
+#pragma unroll
+        for (int f = 0; f < FCO; ++f) fr.a[f] = buf_load4(wr, wo + (uint32_t)f * (16u * 64u));
+#pragma unroll
+        for (int f = 0; f < FPX; ++f) {
+            const int iy = pl[f].y0 + st_kh, ix = pl[f].x0 + kw_lane;
+            const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+            const uint32_t off = (uint32_t)((pl[f].base + iy * p.W + ix) * p.Cs + coff) * 4u;
+            fr.b[f] = buf_load4(xr, ok ? off : 0x80000000u);
+        }
+        ++st_s;
+        if (CMODE == 0) {
+            if (++st_cb == p.cb_per_tap) { st_cb = 0; if (++st_kw == KW) { st_kw = 0; ++st_kh; } }
+        } else {
+            st_kw += 16 / (CMODE ? CMODE : 16);
+            if (st_kw == KW) { st_kw = 0; ++st_kh; }
+        }
+    };
+
+    f32x4 acc[FCO][FPX];
+#pragma unroll
+    for (int i = 0; i < FCO; ++i)
+#pragma unroll
+        for (int j = 0; j < FPX; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto compute = [&](const Frags<FCO, FPX>& fr) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+            for (int i = 0; i < FCO; ++i)
+#pragma unroll
+                for (int j = 0; j < FPX; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(fr.a[i][k], fr.b[j][k], acc[i][j], 0, 0, 0);
+    };
+
+    // Software pipeline, two register sets.  The pair loop body is branch-free so the loads of step s+1
+    // stay ahead of the MFMAs of step s (a `break` between them lets LLVM sink the loads to their use).
+    // Loading one step past s_end is harmless: weights come back 0 from the bounds check or belong to the
+    // next split, and the result is never multiplied in.
+    Frags<FCO, FPX> f0, f1;
+    int s = s_begin;
+    if (s < s_end) {
+        seek(s);
+        load_next(f0);
+        for (; s + 2 <= s_end; s += 2) {
+            load_next(f1);
+            compute(f0);
+            load_next(f0);
+            compute(f1);
+        }
+        if (s < s_end) compute(f0);
+    }
+
+    // ---- epilogue: lane owns channels co0+16i+4kq..+3 of pixel m0+16j+r16 ------------------------------
+    const bool partial = gridDim.y > 1;
+    float* outp = p.out + (partial ? (size_t)blockIdx.y * (size_t)p.M * p.Cout : 0);
+#pragma unroll
+    for (int j = 0; j < FPX; ++j) {
+        const int m = m0 + 16 * j + r16;
+        if (m >= p.M) continue;
+        const int b = m / ohw;
+#pragma unroll
+        for (int i = 0; i < FCO; ++i) {
+            const int co = co0 + 16 * i + 4 * kq;
+            f32x4 v = acc[i][j];
+            if (!partial) {
+                if (p.scale) v *= *reinterpret_cast<const f32x4*>(p.scale + co);
+                if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + co);
+                if (p.tbias && !p.tbias_after_act) v += *reinterpret_cast<const f32x4*>(p.tbias + (size_t)b * p.Cout + co);
+                if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.Cout + co);
+                if (p.act == SBGM_ACT_RELU) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+                }
+                if (p.tbias && p.tbias_after_act) v += *reinterpret_cast<const f32x4*>(p.tbias + (size_t)b * p.Cout + co);
+            }
+            *reinterpret_cast<f32x4*>(outp + (size_t)m * p.Cout + co) = v;
+        }
+    }
+}
+
+// Sum split-K partials [nsplit][M][Cout] and apply the same epilogue.  One float4 per thread.
+__global__ __launch_bounds__(256) void splitk_reduce_epilogue(const ConvParams p, const float* part, int nsplit) {
+    const size_t n4 = (size_t)p.M * p.Cout / 4;
+    const size_t stride = (size_t)p.M * p.Cout;
+    const int ohw = p.OH * p.OW;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i * 4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(part + e);
+        for (int s = 1; s < nsplit; ++s) v += *reinterpret_cast<const f32x4*>(part + s * stride + e);
+        const int m = (int)(e / p.Cout);
+        const int co = (int)(e - (size_t)m * p.Cout);
+        const int b = m / ohw;
+        if (p.scale) v *= *reinterpret_cast<const f32x4*>(p.scale + co);
+        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + co);
+        if (p.tbias && !p.tbias_after_act) v += *reinterpret_cast<const f32x4*>(p.tbias + (size_t)b * p.Cout + co);
+        if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + e);
+        if (p.act == SBGM_ACT_RELU) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+        }
+        if (p.tbias && p.tbias_after_act) v += *reinterpret_cast<const f32x4*>(p.tbias + (size_t)b * p.Cout + co);
+        *reinterpret_cast<f32x4*>(p.out + e) = v;
+    }
+}
+
+// OIHW -> packed [step][Cout][16] (see header comment).  cs = padded input channel count.
+__global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin,
+                                        int KH, int KW, int cs, int nsteps) {
+    const size_t total = (size_t)nsteps * Cout * 16;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int k16 = (int)(i & 15);
+        const int co = (int)((i >> 4) % Cout);
+        const int s = (int)((i >> 4) / Cout);
+        int kh, kw, c;
+        if (cs >= 16) {
+            const int cb_per_tap = cs / 16;
+            const int tap = s / cb_per_tap, cb = s - tap * cb_per_tap;
+            kh = tap / KW; kw = tap - kh * KW; c = cb * 16 + k16;
+        } else if (cs == 4) {
+            kh = s / (KW / 4); kw = (s - kh * (KW / 4)) * 4 + (k16 >> 2); c = k16 & 3;
+        } else {  // cs == 8
+            kh = s / (KW / 2); kw = (s - kh * (KW / 2)) * 2 + (k16 >> 3); c = k16 & 7;
+        }
+        float v = 0.f;
+        if (c < Cin) v = w[(((size_t)co * Cin + c) * KH + kh) * KW + kw];
+        wp[i] = v;
+    }
+}
+
+template <int KH, int KW, int S, int PAD, int CMODE>
+int launch_geom(const ConvParams& p, int fco, int fpx, dim3 grid, hipStream_t st) {
+#define SBGM_TILE(FC, FP)                                                                   \
+    if (fco == FC && fpx == FP) {                                                           \
+        hipLaunchKernelGGL((conv_igemm_kernel<KH, KW, S, PAD, FC, FP, CMODE>), grid, dim3(256), 0, st, p); \
+        return 0;                                                                           \
+    }
+    SBGM_TILE(4, 4) SBGM_TILE(4, 2) SBGM_TILE(4, 1) SBGM_TILE(2, 4) SBGM_TILE(2, 2) SBGM_TILE(2, 1)
+#undef SBGM_TILE
+    return 1;
+}
+
+}  // namespace
+
+int sbgm_conv_nsteps(int KH, int KW, int cs) {
+    if (cs >= 16) return KH * KW * (cs / 16);
+    return KH * (KW / (16 / cs));
+}
+
+int sbgm_launch_pack_conv_weight(const float* w_oihw, float* wp, int Cout, int Cin, int KH, int KW, int cs,
+                                 hipStream_t st) {
+    SBGM_CHECK(cs == 4 || cs == 8 || (cs >= 16 && cs % 16 == 0), "pack_conv_weight: bad padded Cin %d", cs);
+    SBGM_CHECK(cs >= 16 || KW % (16 / cs) == 0, "pack_conv_weight: KW=%d not divisible for cs=%d", KW, cs);
+    SBGM_CHECK(Cin <= cs, "pack_conv_weight: Cin %d > padded %d", Cin, cs);
+    const int nsteps = sbgm_conv_nsteps(KH, KW, cs);
+    const size_t total = (size_t)nsteps * Cout * 16;
+    const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
+    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(blocks), dim3(256), 0, st, w_oihw, wp, Cout, Cin, KH, KW, cs, nsteps);
+    SBGM_LAUNCH_CHECK();
+    return 0;
+}
+
+// Launch one convolution.  `cfg` selects the wave tile and the split-K factor; `partial_ws` must hold
+// splits*M*Cout floats when splits > 1.
+int sbgm_launch_conv(const ConvGeom& g, ConvParams p, const ConvTile& cfg, float* partial_ws, hipStream_t st) {
+    SBGM_CHECK(p.Cout % (16 * cfg.fco) == 0, "conv: Cout=%d not a multiple of the %d-row tile", p.Cout, 16 * cfg.fco);
+    SBGM_CHECK(p.Cs == 4 || p.Cs == 8 || p.Cs % 16 == 0, "conv: padded Cin %d unsupported", p.Cs);
+    SBGM_CHECK(p.act == SBGM_ACT_NONE || p.act == SBGM_ACT_RELU, "conv: only none/relu fuse into the epilogue (act=%d)", p.act);
+    SBGM_CHECK((size_t)p.B * p.H * p.W * p.Cs * 4 < (1ull << 31), "conv: input tensor exceeds 2 GiB buffer window");
+    p.OH = (p.H + 2 * g.pad - g.kh) / g.stride + 1;
+    p.OW = (p.W + 2 * g.pad - g.kw) / g.stride + 1;
+    p.M = p.B * p.OH * p.OW;
+    p.cb_per_tap = p.Cs >= 16 ? p.Cs / 16 : 1;
+    p.nsteps = sbgm_conv_nsteps(g.kh, g.kw, p.Cs);
+    const int splits = std::max(1, std::min(cfg.splits, p.nsteps));
+    p.steps_per_split = (p.nsteps + splits - 1) / splits;
+    const int real_splits = (p.nsteps + p.steps_per_split - 1) / p.steps_per_split;
+    p.n_px_tiles = (p.M + 16 * cfg.fpx - 1) / (16 * cfg.fpx);
+    p.n_co_tiles = p.Cout / (16 * cfg.fco);
+    p.x_bytes = (uint32_t)((size_t)p.B * p.H * p.W * p.Cs * 4);
+    p.w_bytes = (uint32_t)((size_t)p.nsteps * p.Cout * 64);
+    const int ntiles = p.n_px_tiles * p.n_co_tiles;
+    dim3 grid((ntiles + 3) / 4, real_splits);
+    float* final_out = p.out;
+    if (real_splits > 1) {
+        SBGM_CHECK(partial_ws != nullptr, "conv: split-K needs a partial workspace");
+        p.out = partial_ws;
+    }
+    const int cmode = p.Cs >= 16 ? 0 : p.Cs;
+    int rc = 1;
+#define SBGM_GEOM(KH_, KW_, S_, PAD_, CM_)                                                        \
+    if (g.kh == KH_ && g.kw == KW_ && g.stride == S_ && g.pad == PAD_ && cmode == CM_)            \
+        rc = launch_geom<KH_, KW_, S_, PAD_, CM_>(p, cfg.fco, cfg.fpx, grid, st);
+    SBGM_GEOM(8, 8, 2, 3, 0) SBGM_GEOM(8, 8, 2, 3, 4) SBGM_GEOM(8, 8, 2, 3, 8)
+    SBGM_GEOM(3, 3, 1, 1, 0) SBGM_GEOM(3, 3, 2, 1, 0) SBGM_GEOM(1, 1, 2, 0, 0) SBGM_GEOM(1, 1, 1, 0, 0)
+#undef SBGM_GEOM
+    SBGM_CHECK(rc == 0, "conv: no kernel for k=%dx%d s=%d p=%d cs=%d tile=%dx%d", g.kh, g.kw, g.stride, g.pad, p.Cs,
+               cfg.fco, cfg.fpx);
+    SBGM_LAUNCH_CHECK();
+    if (real_splits > 1) {
+        p.out = final_out;
+        const size_t n4 = (size_t)p.M * p.Cout / 4;
+        const int blocks = (int)std::min<size_t>((n4 + 255) / 256, 2048);
+        hipLaunchKernelGGL(splitk_reduce_epilogue, dim3(blocks), dim3(256), 0, st, p, partial_ws, real_splits);
+        SBGM_LAUNCH_CHECK();
+    }
+    return 0;
+}

@@ -1,0 +1,756 @@
+// Host-side engine: owns the repacked weights and the activation workspace, builds the launch sequence of one
+// ScoreNet evaluation for a given (B, H, W) and runs the reverse-SDE sampler loops (optionally as a replayed
+// hipGraph).  Mirrors, at the launch-sequence level, reference sbgm/score_unet.py:247-364 (Encoder.forward),
+// :559-627 (DecoderBlock.forward), :733-758 (Decoder.forward), :829-879 (ScoreNet.forward) and
+// sbgm/score_sampling.py:63-127 / :136-230.
+#include <cmath>
+#include <cstring>
+#include <functional>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/sbgm_hip.h"
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr float BN_EPS = 1e-5f, BN_MOMENTUM = 0.1f, GN_EPS = 1e-5f, LN_EPS = 1e-5f;
+const int FMAP_CH[5] = {64, 64, 128, 256, 512};   // score_unet.py:198
+
+inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+inline int pad_channels(int c) { return c <= 4 ? 4 : c <= 8 ? 8 : (int)align_up(c, 16); }
+
+// ---- parameters ------------------------------------------------------------------------------------------------
+enum ParamKind { P_VEC, P_CONV, P_COUT1, P_IGNORE };
+struct Param {
+    std::string name;
+    ParamKind kind = P_VEC;
+    int64_t numel = 0;          // element count in reference layout
+    int cout = 0, cin = 0, kh = 1, kw = 1, cs = 0;   // P_CONV geometry (cs = padded Cin)
+    float* dev = nullptr;       // engine storage (packed for P_CONV / P_COUT1)
+    size_t dev_floats = 0;
+    bool filled = false;
+};
+
+struct ConvW { Param* w = nullptr; Param* b = nullptr; };          // weight (+ optional bias)
+struct BNW { Param *g, *b, *rm, *rv; float *scale, *bias; };       // + folded eval scale/bias
+struct AttnW { Param *ln1g, *ln1b, *ln2g, *ln2b, *inw, *inb, *outw, *outb, *f1w, *f1b, *f2w, *f2b; int C; };
+struct BlockW { ConvW c1, c2, ds; BNW bn1, bn2, dsbn; bool has_ds; int cin, cout, stride; };
+struct DecW { ConvW up, conv; Param *n1g, *n1b, *n2g, *n2b, *freq, *tpw, *tpb; AttnW attn; bool has_attn; int cin, cout; };
+
+struct ConvOpKey {
+    int kh, kw, s, p, B, H, W, Cs, Cout;
+    bool operator<(const ConvOpKey& o) const { return std::memcmp(this, &o, sizeof(*this)) < 0; }
+};
+
+}  // namespace
+
+struct sbgm_model {
+    sbgm_model_config cfg;
+    int cin_total = 0, cs_in = 0, D = 0;
+    std::vector<std::unique_ptr<Param>> params;
+    std::map<std::string, Param*> by_name;
+    float* arena = nullptr;
+    size_t arena_floats = 0;
+    // structure
+    ConvW conv1, conv2;
+    BNW bn1;
+    std::vector<BlockW> layers[4];
+    Param *enc_freq = nullptr, *label_emb = nullptr;
+    Param *enc_tpw[5], *enc_tpb[5];
+    AttnW enc_attn[5];
+    bool enc_has_attn[5];
+    DecW dec[4];
+    ConvW fin_up, fin_conv;
+    bool bn_dirty = true;
+    // workspace
+    char* ws = nullptr;
+    size_t ws_bytes = 0, ws_used = 0;
+    // sampler state
+    SamplerState* d_state = nullptr;
+    StepScalars* d_table = nullptr;
+    int table_cap = 0;
+    std::map<ConvOpKey, ConvTile> tuned;
+    bool tuning = false;
+    hipStream_t tune_stream = nullptr;
+
+    ~sbgm_model() {
+        if (arena) (void)hipFree(arena);
+        if (ws) (void)hipFree(ws);
+        if (d_state) (void)hipFree(d_state);
+        if (d_table) (void)hipFree(d_table);
+    }
+
+    Param* add(const std::string& name, ParamKind kind, int64_t numel) {
+        params.emplace_back(new Param());
+        Param* p = params.back().get();
+        p->name = name; p->kind = kind; p->numel = numel;
+        by_name[name] = p;
+        return p;
+    }
+    Param* vec(const std::string& n, int64_t numel) { return add(n, P_VEC, numel); }
+    Param* convw(const std::string& n, int cout, int cin, int kh, int kw, int cs = 0) {
+        Param* p = add(n, P_CONV, (int64_t)cout * cin * kh * kw);
+        p->cout = cout; p->cin = cin; p->kh = kh; p->kw = kw;
+        p->cs = cs ? cs : (int)align_up(cin, 16);
+        return p;
+    }
+    BNW bn(const std::string& pre, int c) {
+        BNW b;
+        b.g = vec(pre + ".weight", c); b.b = vec(pre + ".bias", c);
+        b.rm = vec(pre + ".running_mean", c); b.rv = vec(pre + ".running_var", c);
+        add(pre + ".num_batches_tracked", P_IGNORE, 1);
+        b.scale = b.bias = nullptr;
+        return b;
+    }
+    AttnW attn(const std::string& pre, int C) {
+        AttnW a; a.C = C;
+        a.inw = convw(pre + ".mha.in_proj_weight", 3 * C, C, 1, 1);
+        a.inb = vec(pre + ".mha.in_proj_bias", 3 * C);
+        a.outw = convw(pre + ".mha.out_proj.weight", C, C, 1, 1);
+        a.outb = vec(pre + ".mha.out_proj.bias", C);
+        a.ln1g = vec(pre + ".ln1.weight", C); a.ln1b = vec(pre + ".ln1.bias", C);
+        a.ln2g = vec(pre + ".ln2.weight", C); a.ln2b = vec(pre + ".ln2.bias", C);
+        a.f1w = convw(pre + ".ff.0.weight", C, C, 1, 1); a.f1b = vec(pre + ".ff.0.bias", C);
+        a.f2w = convw(pre + ".ff.2.weight", C, C, 1, 1); a.f2b = vec(pre + ".ff.2.bias", C);
+        return a;
+    }
+
+    int build(const sbgm_model_config& c);
+    int ensure_ws(size_t bytes);
+    float* wsalloc(size_t floats) {
+        float* p = reinterpret_cast<float*>(ws + ws_used);
+        ws_used += align_up(floats * 4, 256);
+        return p;
+    }
+    size_t fwd_need(int B, int H, int W) const;
+    size_t sampler_keep(int B, int H, int W) const {
+        const size_t n = (size_t)B * H * W;
+        return align_up(n * 4, 256) * 3 + align_up((size_t)B * 4, 256) + align_up((size_t)B * 8, 256);
+    }
+    size_t ws_need(int B, int H, int W) const { return fwd_need(B, H, W) + sampler_keep(B, H, W); }
+    int fold_bn(hipStream_t st);
+    ConvTile pick_tile(const ConvGeom& g, const ConvParams& p);
+    int conv(const ConvGeom& g, ConvParams p, hipStream_t st);
+    int attention(const AttnW& a, float* x, int B, int S, hipStream_t st);
+    int forward(const float* x, const float* t, const int64_t* y, const float* cond, const float* lsm, const float* topo,
+                float* out, float* const* fmaps_out, int B, int H, int W, int bn_train, hipStream_t st);
+    int sampler(const sbgm_sampler_args& a, hipStream_t st);
+};
+
+int sbgm_model::build(const sbgm_model_config& c) {
+    cfg = c;
+    SBGM_CHECK(c.time_embedding > 0 && c.time_embedding % 2 == 0, "time_embedding=%d must be even", c.time_embedding);
+    SBGM_CHECK(c.last_fmap_channels == 512, "last_fmap_channels=%d: the encoder always emits 512 (score_unet.py:198)",
+               c.last_fmap_channels);
+    SBGM_CHECK(c.n_heads > 0, "n_heads must be positive");
+    D = c.time_embedding;
+    cin_total = 1 + c.n_lsm_channels + c.n_topo_channels + c.n_cond_channels;
+    cs_in = pad_channels(cin_total);
+    SBGM_CHECK(cs_in <= 16, "input channels %d > 16 unsupported", cin_total);
+    // ---- encoder (registration mirrors the reference state_dict names) ------------------------------------------
+    conv1.w = convw("encoder.conv1.weight", 64, cin_total, 8, 8, cs_in);
+    bn1 = bn("encoder.bn1", 64);
+    int cin = 64;
+    for (int li = 0; li < 4; ++li) {
+        const int w = FMAP_CH[li + 1];
+        SBGM_CHECK(c.block_layers[li] >= 1, "block_layers[%d] must be >= 1", li);
+        for (int bi = 0; bi < c.block_layers[li]; ++bi) {
+            const std::string pre = "encoder.layer" + std::to_string(li + 1) + "." + std::to_string(bi);
+            BlockW b;
+            b.cin = cin; b.cout = w; b.stride = (bi == 0 && li > 0) ? 2 : 1;
+            b.c1.w = convw(pre + ".conv1.weight", w, cin, 3, 3);
+            b.bn1 = bn(pre + ".bn1", w);
+            b.c2.w = convw(pre + ".conv2.weight", w, w, 3, 3);
+            b.bn2 = bn(pre + ".bn2", w);
+            b.has_ds = (bi == 0) && (b.stride != 1 || cin != w);
+            if (b.has_ds) {
+                b.ds.w = convw(pre + ".downsample.0.weight", w, cin, 1, 1);
+                b.dsbn = bn(pre + ".downsample.1", w);
+            }
+            layers[li].push_back(b);
+            cin = w;
+        }
+    }
+    enc_freq = vec("encoder.sinusoidal_embedding.W", D / 2);
+    for (int i = 0; i < 5; ++i) {
+        enc_tpw[i] = vec("encoder.time_projection_layers." + std::to_string(i) + ".1.weight", (int64_t)FMAP_CH[i] * D);
+        enc_tpb[i] = vec("encoder.time_projection_layers." + std::to_string(i) + ".1.bias", FMAP_CH[i]);
+    }
+    for (int i = 0; i < 5; ++i) {
+        enc_has_attn[i] = i >= 3;                                                   // score_unet.py:396
+        if (enc_has_attn[i]) {
+            SBGM_CHECK(FMAP_CH[i] % c.n_heads == 0, "channels %d not divisible by heads %d", FMAP_CH[i], c.n_heads);
+            enc_attn[i] = attn("encoder.attention_layers." + std::to_string(i), FMAP_CH[i]);
+        }
+    }
+    conv2.w = convw("encoder.conv2.weight", 64, 64, 8, 8);
+    if (c.num_classes > 0) label_emb = vec("encoder.label_emb.weight", (int64_t)(c.num_classes + 1) * D);
+    // ---- decoder ---------------------------------------------------------------------------------------------------
+    int dc = c.last_fmap_channels;
+    auto dec_block = [&](const std::string& pre, DecW& d, int ci, int co, bool with_norm, bool with_attn) {
+        d.cin = ci; d.cout = co; d.has_attn = with_attn;
+        d.up.w = convw(pre + ".conv_up.weight", ci, ci, 3, 3);
+        d.up.b = vec(pre + ".conv_up.bias", ci);
+        const bool affine = with_norm && c.decoder_norm == SBGM_NORM_GROUP;
+        d.n1g = affine ? vec(pre + ".norm1.weight", ci) : nullptr;
+        d.n1b = affine ? vec(pre + ".norm1.bias", ci) : nullptr;
+        if (co == 1) {
+            d.conv.w = add(pre + ".conv.weight", P_COUT1, (int64_t)ci * 9);
+            d.conv.w->cin = ci;
+        } else {
+            d.conv.w = convw(pre + ".conv.weight", co, ci, 3, 3);
+        }
+        d.conv.b = vec(pre + ".conv.bias", co);
+        d.n2g = affine ? vec(pre + ".norm2.weight", co) : nullptr;
+        d.n2b = affine ? vec(pre + ".norm2.bias", co) : nullptr;
+        d.freq = vec(pre + ".sinusoidal_embedding.W", D / 2);
+        d.tpw = vec(pre + ".time_projection_layer.1.weight", (int64_t)co * D);
+        d.tpb = vec(pre + ".time_projection_layer.1.bias", co);
+        if (with_attn) {
+            SBGM_CHECK(co % c.n_heads == 0, "channels %d not divisible by heads %d", co, c.n_heads);
+            d.attn = attn(pre + ".attention", co);
+        }
+        return 0;
+    };
+    for (int i = 0; i < 4; ++i) {
+        const int co = i != 3 ? dc / 2 : 64;
+        if (dec_block("decoder.residual_layers." + std::to_string(i), dec[i], dc, co, true, i < 2)) return 1;
+        dc = co;
+    }
+    DecW fin;
+    if (dec_block("decoder.final_layer", fin, dec[3].cin, 1, false, false)) return 1;
+    // final layer: its time-embedding tensors exist in the state_dict but are never used (score_unet.py:757)
+    fin.freq->kind = fin.tpw->kind = fin.tpb->kind = P_IGNORE;
+    fin_up = fin.up; fin_conv = fin.conv;
+
+    // ---- storage ----------------------------------------------------------------------------------------------------
+    size_t total = 0;
+    for (auto& up : params) {
+        Param* p = up.get();
+        if (p->kind == P_CONV) p->dev_floats = (size_t)sbgm_conv_nsteps(p->kh, p->kw, p->cs) * p->cout * 16;
+        else if (p->kind == P_IGNORE) p->dev_floats = 0;
+        else p->dev_floats = (size_t)p->numel;
+        total += align_up(p->dev_floats, 64);
+    }
+    // folded BN scale/bias
+    size_t bn_floats = 0;
+    auto count_bn = [&](BNW& b, int c_) { bn_floats += 2 * align_up((size_t)c_, 64); (void)b; };
+    count_bn(bn1, 64);
+    for (int li = 0; li < 4; ++li)
+        for (auto& b : layers[li]) { count_bn(b.bn1, b.cout); count_bn(b.bn2, b.cout); if (b.has_ds) count_bn(b.dsbn, b.cout); }
+    arena_floats = total + bn_floats + 64;
+    SBGM_HIP(hipMalloc(&arena, arena_floats * 4));
+    SBGM_HIP(hipMemset(arena, 0, arena_floats * 4));
+    size_t off = 0;
+    for (auto& up : params) {
+        Param* p = up.get();
+        if (p->dev_floats) { p->dev = arena + off; off += align_up(p->dev_floats, 64); }
+        if (p->kind == P_IGNORE) p->filled = true;
+    }
+    auto place_bn = [&](BNW& b, int c_) {
+        b.scale = arena + off; off += align_up((size_t)c_, 64);
+        b.bias = arena + off; off += align_up((size_t)c_, 64);
+    };
+    place_bn(bn1, 64);
+    for (int li = 0; li < 4; ++li)
+        for (auto& b : layers[li]) { place_bn(b.bn1, b.cout); place_bn(b.bn2, b.cout); if (b.has_ds) place_bn(b.dsbn, b.cout); }
+    SBGM_HIP(hipMalloc(&d_state, sizeof(SamplerState)));
+    return 0;
+}
+
+int sbgm_model::ensure_ws(size_t bytes) {
+    if (bytes <= ws_bytes) return 0;
+    if (ws) SBGM_HIP(hipFree(ws));
+    ws = nullptr; ws_bytes = 0;
+    SBGM_HIP(hipMalloc(&ws, bytes));
+    ws_bytes = bytes;
+    return 0;
+}
+
+// generous upper bound: every intermediate gets its own slab (no liveness reuse yet)
+size_t sbgm_model::fwd_need(int B, int H, int W) const {
+    const size_t px = (size_t)B * H * W;
+    // NHWC floats per input pixel summed over all intermediates (encoder ~ 64/4*3 + ..., decoder dominated by the
+    // final block's 3 x 64 channels at full resolution); 1024 floats/pixel is > 2x the true footprint.
+    return px * 1024 * 4 + (64u << 20);
+}
+
+int sbgm_model::fold_bn(hipStream_t st) {
+    auto f = [&](BNW& b, int c) {
+        return sbgm_launch_bn_fold(b.g->dev, b.b->dev, b.rm->dev, b.rv->dev, BN_EPS, b.scale, b.bias, c, st);
+    };
+    if (f(bn1, 64)) return 1;
+    for (int li = 0; li < 4; ++li)
+        for (auto& b : layers[li]) {
+            if (f(b.bn1, b.cout) || f(b.bn2, b.cout)) return 1;
+            if (b.has_ds && f(b.dsbn, b.cout)) return 1;
+        }
+    bn_dirty = false;
+    return 0;
+}
+
+// Static heuristic: fill ~2 waves per SIMD (2048 waves) with the largest tile that gets there; use split-K for the
+// small-spatial layers whose M*Cout is too small even with small tiles.
+ConvTile sbgm_model::pick_tile(const ConvGeom& g, const ConvParams& p) {
+    const int OH = (p.H + 2 * g.pad - g.kh) / g.stride + 1, OW = (p.W + 2 * g.pad - g.kw) / g.stride + 1;
+    ConvOpKey key{g.kh, g.kw, g.stride, g.pad, p.B, p.H, p.W, p.Cs, p.Cout};
+    auto it = tuned.find(key);
+    if (it != tuned.end()) return it->second;
+    const int M = p.B * OH * OW;
+    const int nsteps = sbgm_conv_nsteps(g.kh, g.kw, p.Cs);
+    const int target = 2048;
+    const int cand[4][2] = {{4, 4}, {4, 2}, {2, 2}, {2, 1}};
+    for (auto& c : cand) {
+        if (p.Cout % (16 * c[0])) continue;
+        const long tiles = (long)((M + 16 * c[1] - 1) / (16 * c[1])) * (p.Cout / (16 * c[0]));
+        if (tiles >= target) return ConvTile{c[0], c[1], 1};
+    }
+    // small problem: 64x32 tiles + split-K (>= 4 K-steps per split)
+    int fco = p.Cout % 64 == 0 ? 4 : 2, fpx = 2;
+    long tiles = (long)((M + 16 * fpx - 1) / (16 * fpx)) * (p.Cout / (16 * fco));
+    if (tiles * (nsteps / 4) < target / 2) { fpx = 1; tiles = (long)((M + 15) / 16) * (p.Cout / (16 * fco)); }
+    int splits = (int)std::min<long>(std::max<long>(1, target / std::max<long>(1, tiles)), std::max(1, nsteps / 4));
+    return ConvTile{fco, fpx, splits};
+}
+
+int sbgm_model::conv(const ConvGeom& g, ConvParams p, hipStream_t st) {
+    const int OH = (p.H + 2 * g.pad - g.kh) / g.stride + 1, OW = (p.W + 2 * g.pad - g.kw) / g.stride + 1;
+    const size_t mc = (size_t)p.B * OH * OW * p.Cout;
+    if (tuning) {
+        // time every candidate on this op, keep the fastest
+        ConvOpKey key{g.kh, g.kw, g.stride, g.pad, p.B, p.H, p.W, p.Cs, p.Cout};
+        if (tuned.find(key) == tuned.end()) {
+            const int nsteps = sbgm_conv_nsteps(g.kh, g.kw, p.Cs);
+            std::vector<ConvTile> cands;
+            const int tiles[6][2] = {{4, 4}, {4, 2}, {4, 1}, {2, 4}, {2, 2}, {2, 1}};
+            for (auto& t : tiles) {
+                if (p.Cout % (16 * t[0])) continue;
+                for (int sp : {1, 2, 3, 4, 6, 8, 12, 16, 24, 32}) {
+                    if (sp > 1 && nsteps / sp < 2) continue;
+                    const long ntile = (long)(((size_t)p.B * OH * OW + 16 * t[1] - 1) / (16 * t[1])) * (p.Cout / (16 * t[0]));
+                    if (sp > 1 && ntile * sp > 16384) continue;      // pointless: already far more waves than SIMDs
+                    cands.push_back(ConvTile{t[0], t[1], sp});
+                }
+            }
+            hipEvent_t e0, e1;
+            SBGM_HIP(hipEventCreate(&e0));
+            SBGM_HIP(hipEventCreate(&e1));
+            float best = 1e30f;
+            ConvTile best_t = pick_tile(g, p);
+            float* part = nullptr;
+            for (auto& ct : cands) {
+                const size_t need = ct.splits > 1 ? mc * ct.splits : 0;
+                const size_t save = ws_used;
+                if (ws_used + need * 4 + 256 > ws_bytes) continue;
+                part = need ? wsalloc(need) : nullptr;
+                for (int rep = 0; rep < 4; ++rep) {
+                    if (rep == 1) SBGM_HIP(hipEventRecord(e0, st));
+                    if (sbgm_launch_conv(g, p, ct, part, st)) return 1;
+                }
+                SBGM_HIP(hipEventRecord(e1, st));
+                SBGM_HIP(hipEventSynchronize(e1));
+                float ms = 0.f;
+                SBGM_HIP(hipEventElapsedTime(&ms, e0, e1));
+                if (ms < best) { best = ms; best_t = ct; }
+                ws_used = save;
+            }
+            (void)hipEventDestroy(e0);
+            (void)hipEventDestroy(e1);
+            tuned[key] = best_t;
+        }
+    }
+    const ConvTile ct = pick_tile(g, p);
+    float* part = nullptr;
+    if (ct.splits > 1) part = wsalloc(mc * ct.splits);
+    return sbgm_launch_conv(g, p, ct, part, st);
+}
+
+// y = h + FF(LN2(h)),  h = x + MHA(LN1(x))   over tokens [B*S, C]  (score_unet.py:136-148); in place on x
+int sbgm_model::attention(const AttnW& a, float* x, int B, int S, hipStream_t st) {
+    const int C = a.C, M = B * S;
+    float* n1 = wsalloc((size_t)M * C);
+    float* qkv = wsalloc((size_t)M * 3 * C);
+    float* att = wsalloc((size_t)M * C);
+    float* h = wsalloc((size_t)M * C);
+    float* f1 = wsalloc((size_t)M * C);
+    const ConvGeom lin{1, 1, 1, 0};
+    if (sbgm_launch_layernorm(x, n1, a.ln1g->dev, a.ln1b->dev, M, C, LN_EPS, st)) return 1;
+    ConvParams p{};
+    p.B = 1; p.H = 1; p.W = M; p.Cs = C;
+    p.x = n1; p.wp = a.inw->dev; p.out = qkv; p.bias = a.inb->dev; p.Cout = 3 * C;
+    if (conv(lin, p, st)) return 1;
+    if (sbgm_launch_mha_core(qkv, att, B, S, C, cfg.n_heads, st)) return 1;
+    p.x = att; p.wp = a.outw->dev; p.out = h; p.bias = a.outb->dev; p.Cout = C; p.res = x;
+    if (conv(lin, p, st)) return 1;
+    if (sbgm_launch_layernorm(h, n1, a.ln2g->dev, a.ln2b->dev, M, C, LN_EPS, st)) return 1;
+    p.x = n1; p.wp = a.f1w->dev; p.out = f1; p.bias = a.f1b->dev; p.res = nullptr;
+    if (conv(lin, p, st)) return 1;
+    if (sbgm_launch_act(f1, (size_t)M * C, SBGM_ACT_GELU, st)) return 1;
+    p.x = f1; p.wp = a.f2w->dev; p.out = x; p.bias = a.f2b->dev; p.res = h;
+    return conv(lin, p, st);
+}
+
+int sbgm_model::forward(const float* x, const float* t, const int64_t* y, const float* cond, const float* lsm,
+                        const float* topo, float* out, float* const* fmaps_out, int B, int H, int W, int bn_train,
+                        hipStream_t st) {
+    SBGM_CHECK(B >= 1 && H >= 32 && W >= 32 && H % 32 == 0 && W % 32 == 0,
+               "forward: H,W must be positive multiples of 32 (five stride-2 stages), got B=%d H=%d W=%d", B, H, W);
+    SBGM_CHECK(x && t && out, "forward: x, t and out are required");
+    SBGM_CHECK((cfg.n_cond_channels > 0) == (cond != nullptr), "forward: cond_img presence does not match the model (%d channels)", cfg.n_cond_channels);
+    SBGM_CHECK((cfg.n_lsm_channels > 0) == (lsm != nullptr), "forward: lsm_cond presence does not match the model");
+    SBGM_CHECK((cfg.n_topo_channels > 0) == (topo != nullptr), "forward: topo_cond presence does not match the model");
+    SBGM_CHECK(!(y && !label_emb), "forward: y given but the model has no label embedding");
+    if (sbgm_model_check_complete(this)) return 1;
+    if (!tuning) {
+        SBGM_CHECK(fwd_need(B, H, W) <= ws_bytes, "forward: workspace not prepared for B=%d H=%d W=%d", B, H, W);
+        ws_used = 0;
+    }
+    if (bn_dirty && fold_bn(st)) return 1;
+
+    // ---- pack inputs, time embedding -------------------------------------------------------------------------------
+    PackSrc src{};
+    auto push = [&](const float* p, int c) { if (p && c) { src.ptr[src.n] = p; src.ch[src.n] = c; ++src.n; } };
+    push(x, 1); push(lsm, cfg.n_lsm_channels); push(topo, cfg.n_topo_channels); push(cond, cfg.n_cond_channels);
+    float* x0 = wsalloc((size_t)B * H * W * cs_in);
+    if (sbgm_launch_pack_input(src, x0, B, H, W, cs_in, st)) return 1;
+
+    TimeEmbedArgs te{};
+    te.t = t; te.y = y; te.label_emb = (y && label_emb) ? label_emb->dev : nullptr;
+    te.B = B; te.D = D;
+    te.n_emb = 5;
+    te.freqs[0] = enc_freq->dev;
+    for (int i = 0; i < 4; ++i) te.freqs[1 + i] = dec[i].freq->dev;
+    te.emb_ws = wsalloc((size_t)5 * B * D);
+    float* tb[9];
+    te.n_proj = 9;
+    for (int i = 0; i < 5; ++i) {
+        tb[i] = wsalloc((size_t)B * FMAP_CH[i]);
+        te.proj[i] = TimeProj{enc_tpw[i]->dev, enc_tpb[i]->dev, tb[i], FMAP_CH[i], 0};
+    }
+    for (int i = 0; i < 4; ++i) {
+        tb[5 + i] = wsalloc((size_t)B * dec[i].cout);
+        te.proj[5 + i] = TimeProj{dec[i].tpw->dev, dec[i].tpb->dev, tb[5 + i], dec[i].cout, 1 + i};
+    }
+    if (sbgm_launch_time_embed(te, st)) return 1;
+
+    // 24 B per statistic: B*G for GroupNorm (G = C for InstanceNorm), C for BatchNorm
+    const size_t n_stats = std::max<size_t>(512, (size_t)B * (cfg.decoder_norm == SBGM_NORM_GROUP ? std::min(cfg.gn_groups, 512) : 512));
+    double* stats = reinterpret_cast<double*>(wsalloc(n_stats * 6));
+
+    // conv + BatchNorm (+res, relu, late time bias): eval folds BN into the conv epilogue, train runs it after
+    auto conv_bn = [&](const ConvGeom& g, const float* in, int h, int w, int cs, const ConvW& cw, BNW& bnw, int cout,
+                       const float* res, bool relu, const float* tb_after, float* o) -> int {
+        ConvParams p{};
+        p.x = in; p.wp = cw.w->dev; p.B = B; p.H = h; p.W = w; p.Cs = cs; p.Cout = cout;
+        if (!bn_train) {
+            p.out = o; p.scale = bnw.scale; p.bias = bnw.bias; p.res = res; p.act = relu ? SBGM_ACT_RELU : SBGM_ACT_NONE;
+            p.tbias = tb_after; p.tbias_after_act = 1;
+            return conv(g, p, st);
+        }
+        const int oh = (h + 2 * g.pad - g.kh) / g.stride + 1, ow = (w + 2 * g.pad - g.kw) / g.stride + 1;
+        float* raw = wsalloc((size_t)B * oh * ow * cout);
+        p.out = raw;
+        if (conv(g, p, st)) return 1;
+        return sbgm_launch_batchnorm_train(raw, o, bnw.g->dev, bnw.b->dev, bnw.rm->dev, bnw.rv->dev, res, tb_after, relu, B,
+                                           oh * ow, cout, BN_EPS, BN_MOMENTUM, stats, st);
+    };
+
+    // ---- encoder ------------------------------------------------------------------------------------------------------
+    float* fm[5];
+    int fh[5], fw[5];
+    fh[0] = H / 2; fw[0] = W / 2;
+    fm[0] = wsalloc((size_t)B * fh[0] * fw[0] * 64);
+    {
+        ConvParams p{};
+        p.x = x0; p.wp = conv1.w->dev; p.out = fm[0]; p.tbias = tb[0]; p.B = B; p.H = H; p.W = W; p.Cs = cs_in; p.Cout = 64;
+        if (conv(ConvGeom{8, 8, 2, 3}, p, st)) return 1;                                        // score_unet.py:312-316
+    }
+    int ch = H / 4, cw_ = W / 4;
+    float* cur = wsalloc((size_t)B * ch * cw_ * 64);
+    if (conv_bn(ConvGeom{8, 8, 2, 3}, fm[0], fh[0], fw[0], 64, conv2, bn1, 64, nullptr, true, nullptr, cur)) return 1;   // :321-325
+    int cc = 64;
+    for (int li = 0; li < 4; ++li) {
+        const int nb = (int)layers[li].size();
+        for (int bi = 0; bi < nb; ++bi) {
+            BlockW& b = layers[li][bi];
+            const int oh = ch / b.stride, ow = cw_ / b.stride;
+            float* y1 = wsalloc((size_t)B * oh * ow * b.cout);
+            if (conv_bn(ConvGeom{3, 3, b.stride, 1}, cur, ch, cw_, cc, b.c1, b.bn1, b.cout, nullptr, true, nullptr, y1)) return 1;
+            const float* idn = cur;
+            if (b.has_ds) {
+                float* d = wsalloc((size_t)B * oh * ow * b.cout);
+                if (conv_bn(ConvGeom{1, 1, b.stride, 0}, cur, ch, cw_, cc, b.ds, b.dsbn, b.cout, nullptr, false, nullptr, d)) return 1;
+                idn = d;
+            }
+            float* y2 = wsalloc((size_t)B * oh * ow * b.cout);
+            const float* tba = (bi == nb - 1) ? tb[li + 1] : nullptr;                        // fmap + t_emb (:332,341,350,359)
+            if (conv_bn(ConvGeom{3, 3, 1, 1}, y1, oh, ow, b.cout, b.c2, b.bn2, b.cout, idn, true, tba, y2)) return 1;
+            cur = y2; ch = oh; cw_ = ow; cc = b.cout;
+        }
+        if (enc_has_attn[li + 1] && attention(enc_attn[li + 1], cur, B, ch * cw_, st)) return 1;
+        fm[li + 1] = cur; fh[li + 1] = ch; fw[li + 1] = cw_;
+    }
+    if (fmaps_out) {
+        for (int i = 0; i < 5; ++i)
+            if (fmaps_out[i])
+                SBGM_HIP(hipMemcpyAsync(fmaps_out[i], fm[i], (size_t)B * fh[i] * fw[i] * FMAP_CH[i] * 4, hipMemcpyDeviceToDevice, st));
+    }
+
+    // ---- decoder ------------------------------------------------------------------------------------------------------
+    const int G_of = cfg.gn_groups;
+    auto groups = [&](int c) { return cfg.decoder_norm == SBGM_NORM_GROUP ? std::max(1, std::min(G_of, c)) : c; };
+    cur = fm[4]; ch = fh[4]; cw_ = fw[4];
+    for (int i = 0; i < 4; ++i) {
+        DecW& d = dec[i];
+        const int oh = 2 * ch, ow = 2 * cw_;
+        SBGM_CHECK(oh == fh[3 - i] && ow == fw[3 - i] && d.cout == FMAP_CH[3 - i], "decoder/skip shape mismatch at block %d", i);
+        float* up = wsalloc((size_t)B * oh * ow * d.cin);
+        if (sbgm_launch_upsample2x(cur, up, B, ch, cw_, d.cin, st)) return 1;
+        float* a = wsalloc((size_t)B * oh * ow * d.cin);
+        ConvParams p{};
+        p.x = up; p.wp = d.up.w->dev; p.out = a; p.bias = d.up.b->dev; p.B = B; p.H = oh; p.W = ow; p.Cs = d.cin; p.Cout = d.cin;
+        if (conv(ConvGeom{3, 3, 1, 1}, p, st)) return 1;
+        if (sbgm_launch_groupnorm(a, a, d.n1g ? d.n1g->dev : nullptr, d.n1b ? d.n1b->dev : nullptr, nullptr, nullptr,
+                                  SBGM_ACT_NONE, B, oh * ow, d.cin, groups(d.cin), GN_EPS, stats, st)) return 1;
+        float* c2 = wsalloc((size_t)B * oh * ow * d.cout);
+        p.x = a; p.wp = d.conv.w->dev; p.out = c2; p.bias = d.conv.b->dev; p.Cout = d.cout;
+        if (conv(ConvGeom{3, 3, 1, 1}, p, st)) return 1;
+        if (sbgm_launch_groupnorm(c2, c2, d.n2g ? d.n2g->dev : nullptr, d.n2b ? d.n2b->dev : nullptr, fm[3 - i], tb[5 + i],
+                                  cfg.decoder_activation, B, oh * ow, d.cout, groups(d.cout), GN_EPS, stats, st)) return 1;
+        if (d.has_attn && attention(d.attn, c2, B, oh * ow, st)) return 1;
+        cur = c2; ch = oh; cw_ = ow;
+    }
+    {   // final block: no norms, no skip, no time, identity activation (score_unet.py:726-730, :757)
+        const int ci = dec[3].cout;
+        float* up = wsalloc((size_t)B * H * W * ci);
+        if (sbgm_launch_upsample2x(cur, up, B, ch, cw_, ci, st)) return 1;
+        float* a = wsalloc((size_t)B * H * W * ci);
+        ConvParams p{};
+        p.x = up; p.wp = fin_up.w->dev; p.out = a; p.bias = fin_up.b->dev; p.B = B; p.H = H; p.W = W; p.Cs = ci; p.Cout = ci;
+        if (conv(ConvGeom{3, 3, 1, 1}, p, st)) return 1;
+        if (sbgm_launch_conv3x3_cout1(a, fin_conv.w->dev, fin_conv.b->dev, t, cfg.sigma, out, B, H, W, ci, st)) return 1;
+    }
+    return 0;
+}
+
+// torch.linspace(start, end, n) in fp32, as ATen fills it (symmetric about the midpoint)
+static std::vector<float> linspace_f32(float start, float end, int n) {
+    std::vector<float> v(n);
+    if (n == 1) { v[0] = start; return v; }
+    const float step = (end - start) / (float)(n - 1);
+    const int half = n / 2;
+    for (int i = 0; i < n; ++i) v[i] = i < half ? start + step * (float)i : end - step * (float)(n - 1 - i);
+    return v;
+}
+
+int sbgm_model::sampler(const sbgm_sampler_args& a, hipStream_t st) {
+    SBGM_CHECK(a.kind == SBGM_SAMPLER_EM || a.kind == SBGM_SAMPLER_PC, "sampler: unknown kind %d", a.kind);
+    SBGM_CHECK(a.num_steps >= 2, "sampler: num_steps=%d must be >= 2 (step size = t0 - t1)", a.num_steps);
+    SBGM_CHECK(a.out != nullptr, "sampler: out is required");
+    const int B = a.B, H = a.H, W = a.W, N = a.num_steps;
+    const size_t per = (size_t)H * W, n = (size_t)B * per;
+    SBGM_CHECK(ws_need(B, H, W) <= ws_bytes, "sampler: workspace not prepared for B=%d H=%d W=%d", B, H, W);
+    // ---- per-step scalars on the host, in the reference's precision --------------------------------------------------
+    std::vector<StepScalars> tab(N);
+    const float sig = cfg.sigma;
+    if (a.kind == SBGM_SAMPLER_EM) {                       // score_sampling.py:96-97, :102-103, :124-125
+        const std::vector<float> ts = linspace_f32(1.0f, a.eps, N);
+        const float dt = ts[0] - ts[1];
+        for (int i = 0; i < N; ++i) {
+            const float g = powf(sig, ts[i]);
+            tab[i] = StepScalars{ts[i], g * g, dt, sqrtf(dt) * g, ts[std::min(i + 1, N - 1)]};
+        }
+    } else {                                               // score_sampling.py:169-170, :176, :207, :224-227
+        std::vector<double> ts(N);
+        const double step = ((double)a.eps - 1.0) / (double)(N - 1);
+        for (int i = 0; i < N; ++i) ts[i] = 1.0 + (double)i * step;
+        ts[N - 1] = (double)a.eps;
+        const float dt = (float)(ts[0] - ts[1]);
+        for (int i = 0; i < N; ++i) {
+            const float tf = (float)ts[i];
+            const float g = powf(sig, tf);
+            tab[i] = StepScalars{tf, g * g, dt, sqrtf((g * g) * dt), (float)ts[std::min(i + 1, N - 1)]};
+        }
+    }
+    if (table_cap < N) {
+        if (d_table) SBGM_HIP(hipFree(d_table));
+        d_table = nullptr;
+        SBGM_HIP(hipMalloc(&d_table, sizeof(StepScalars) * N));
+        table_cap = N;
+    }
+    SBGM_HIP(hipMemcpyAsync(d_table, tab.data(), sizeof(StepScalars) * N, hipMemcpyHostToDevice, st));
+    SBGM_HIP(hipMemsetAsync(d_state, 0, sizeof(SamplerState), st));
+    SBGM_HIP(hipStreamSynchronize(st));                   // tab is a stack-lifetime host buffer
+
+    // persistent sampler buffers live at the top of the workspace, the forward uses the rest
+    const size_t keep = sampler_keep(B, H, W);
+    char* top = ws + ws_bytes - keep;
+    float* xs = reinterpret_cast<float*>(top);
+    float* score = reinterpret_cast<float*>(top + align_up(n * 4, 256));
+    float* xmean = reinterpret_cast<float*>(top + 2 * align_up(n * 4, 256));
+    float* t_dev = reinterpret_cast<float*>(top + 3 * align_up(n * 4, 256));
+    double* sumsq = reinterpret_cast<double*>(top + 3 * align_up(n * 4, 256) + align_up((size_t)B * 4, 256));
+    const size_t fwd_bytes = ws_bytes - keep;
+    if (bn_dirty && fold_bn(st)) return 1;              // keep the fold out of the captured step
+
+    // x0 = randn * marginal_prob_std(1)
+    const float ls = logf(sig);
+    const float std1 = fmaxf(sqrtf((expf((2.f * 1.0f) * ls) - 1.f) / (2.f * ls)), 1e-5f);
+    const float* z = a.noise;
+    size_t draw = 0;
+    auto next_z = [&]() -> const float* { const float* p = z ? z + draw * n : nullptr; ++draw; return p; };
+    if (sbgm_launch_init_noise(xs, std1, next_z(), a.seed, d_state, 0, n, st)) return 1;
+    if (sbgm_launch_fill_t(t_dev, tab[0].t, B, st)) return 1;
+    const float snr_nn = (float)((double)a.snr * std::sqrt((double)per));     // snr * sqrt(prod(x.shape[1:])) (:202-203)
+
+    auto one_step = [&](bool with_noise_ptrs) -> int {
+        if (a.kind == SBGM_SAMPLER_PC) {
+            if (forward(xs, t_dev, a.y, a.cond_img, a.lsm_cond, a.topo_cond, score, nullptr, B, H, W, a.bn_train, st)) return 1;
+            if (sbgm_launch_langevin(xs, score, with_noise_ptrs ? next_z() : nullptr, snr_nn, sumsq, d_state, 0, a.seed, B, per, st)) return 1;
+        }
+        if (forward(xs, t_dev, a.y, a.cond_img, a.lsm_cond, a.topo_cond, score, nullptr, B, H, W, a.bn_train, st)) return 1;
+        return sbgm_launch_em_update(xs, xmean, score, with_noise_ptrs ? next_z() : nullptr, d_table, d_state, nullptr, 0, t_dev,
+                                     a.seed, B, per, N, st);
+    };
+
+    const size_t saved_ws = ws_bytes;
+    ws_bytes = fwd_bytes;            // forward() must not touch the sampler slabs
+    int rc = 0;
+    if (a.use_graph && !z) {
+        hipGraph_t graph = nullptr;
+        hipGraphExec_t exec = nullptr;
+        hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+        if (e == hipSuccess) {
+            rc = one_step(false);
+            hipError_t e2 = hipStreamEndCapture(st, &graph);
+            if (rc == 0 && e2 == hipSuccess && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                for (int i = 0; i < N && rc == 0; ++i)
+                    if (hipGraphLaunch(exec, st) != hipSuccess) { sbgm_set_error("hipGraphLaunch failed at step %d", i); rc = 2; }
+            } else if (rc == 0) {
+                sbgm_set_error("hipGraph capture/instantiate failed: %s", hipGetErrorString(e2));
+                rc = 2;
+            }
+            if (exec) (void)hipGraphExecDestroy(exec);
+            if (graph) (void)hipGraphDestroy(graph);
+        } else {
+            sbgm_set_error("hipStreamBeginCapture failed: %s", hipGetErrorString(e));
+            rc = 2;
+        }
+    } else {
+        for (int i = 0; i < N && rc == 0; ++i) rc = one_step(z != nullptr);
+    }
+    ws_bytes = saved_ws;
+    if (rc) return rc;
+    SBGM_HIP(hipMemcpyAsync(a.out, xmean, n * 4, hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+// =====================================================================================================================
+// C ABI
+// =====================================================================================================================
+const char* sbgm_get_error();
+extern "C" {
+
+const char* sbgm_last_error(void) { return sbgm_get_error(); }
+int sbgm_abi_version(void) { return 1; }
+
+int sbgm_model_create(const sbgm_model_config* cfg, sbgm_model** out) {
+    SBGM_CHECK(cfg && out, "model_create: null argument");
+    std::unique_ptr<sbgm_model> m(new sbgm_model());
+    if (m->build(*cfg)) return 1;
+    *out = m.release();
+    return 0;
+}
+void sbgm_model_destroy(sbgm_model* m) { delete m; }
+int sbgm_model_num_params(const sbgm_model* m) { return (int)m->params.size(); }
+const char* sbgm_model_param_name(const sbgm_model* m, int i) {
+    return (i >= 0 && i < (int)m->params.size()) ? m->params[i]->name.c_str() : nullptr;
+}
+int64_t sbgm_model_param_numel(const sbgm_model* m, int i) {
+    return (i >= 0 && i < (int)m->params.size()) ? m->params[i]->numel : -1;
+}
+
+int sbgm_model_set_param(sbgm_model* m, const char* name, const void* data, int64_t numel, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    auto it = m->by_name.find(name);
+    SBGM_CHECK(it != m->by_name.end(), "set_param: unexpected key '%s'", name);
+    Param* p = it->second;
+    if (p->kind == P_IGNORE) return 0;
+    SBGM_CHECK(numel == p->numel, "set_param: '%s' has %lld elements, expected %lld", name, (long long)numel, (long long)p->numel);
+    const float* src = static_cast<const float*>(data);
+    if (p->kind == P_VEC) {
+        SBGM_HIP(hipMemcpyAsync(p->dev, src, (size_t)numel * 4, hipMemcpyDeviceToDevice, st));
+    } else if (p->kind == P_CONV) {
+        if (sbgm_launch_pack_conv_weight(src, p->dev, p->cout, p->cin, p->kh, p->kw, p->cs, st)) return 1;
+    } else {
+        if (sbgm_launch_pack_cout1_weight(src, p->dev, p->cin, st)) return 1;
+    }
+    p->filled = true;
+    m->bn_dirty = true;
+    return 0;
+}
+
+int sbgm_model_get_param(sbgm_model* m, const char* name, float* dst, int64_t numel, void* stream) {
+    auto it = m->by_name.find(name);
+    SBGM_CHECK(it != m->by_name.end(), "get_param: unknown key '%s'", name);
+    Param* p = it->second;
+    SBGM_CHECK(p->kind == P_VEC && numel == p->numel, "get_param: '%s' is not a plain vector of %lld elements", name, (long long)numel);
+    SBGM_HIP(hipMemcpyAsync(dst, p->dev, (size_t)numel * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
+int sbgm_model_check_complete(const sbgm_model* m) {
+    for (auto& p : m->params) SBGM_CHECK(p->filled, "model: state_dict entry '%s' was never uploaded", p->name.c_str());
+    return 0;
+}
+
+int sbgm_model_forward(sbgm_model* m, const float* x, const float* t, const int64_t* y, const float* cond_img,
+                       const float* lsm_cond, const float* topo_cond, float* out, float* const* fmaps, int B, int H, int W,
+                       int bn_train, void* stream) {
+    if (m->ensure_ws(m->ws_need(B, H, W))) return 1;
+    return m->forward(x, t, y, cond_img, lsm_cond, topo_cond, out, fmaps, B, H, W, bn_train, (hipStream_t)stream);
+}
+
+int sbgm_sampler_run(sbgm_model* m, const sbgm_sampler_args* a, void* stream) {
+    SBGM_CHECK(a, "sampler_run: null args");
+    if (m->ensure_ws(m->ws_need(a->B, a->H, a->W))) return 1;
+    return m->sampler(*a, (hipStream_t)stream);
+}
+
+int sbgm_model_autotune(sbgm_model* m, int B, int H, int W, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (m->ensure_ws(2 * m->ws_need(B, H, W))) return 1;
+    // dummy inputs: zero-filled slabs at the top of the workspace
+    const size_t px = (size_t)B * H * W;
+    const size_t in_floats = px * 16 + 1024;
+    float* inp = reinterpret_cast<float*>(m->ws + m->ws_bytes - align_up(in_floats * 4, 256));
+    SBGM_HIP(hipMemsetAsync(inp, 0, in_floats * 4, st));
+    float* x = inp; float* t = inp + px; float* cond = t + 1024; float* lsm = cond + px * 8; float* topo = lsm + px * 2;
+    float* out = topo + px * 2;
+    if (sbgm_launch_fill_t(t, 0.5f, B, st)) return 1;
+    const size_t saved = m->ws_bytes;
+    m->ws_bytes -= align_up(in_floats * 4, 256);
+    m->tuning = true;
+    m->ws_used = 0;
+    const int rc = m->forward(x, t, nullptr, m->cfg.n_cond_channels ? cond : nullptr, m->cfg.n_lsm_channels ? lsm : nullptr,
+                              m->cfg.n_topo_channels ? topo : nullptr, out, nullptr, B, H, W, 0, st);
+    m->tuning = false;
+    m->ws_bytes = saved;
+    SBGM_HIP(hipStreamSynchronize(st));
+    return rc;
+}
+
+int sbgm_event_create(void** ev) { hipEvent_t e; SBGM_HIP(hipEventCreate(&e)); *ev = e; return 0; }
+int sbgm_event_record(void* ev, void* stream) { SBGM_HIP(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream)); return 0; }
+int sbgm_event_elapsed_ms(void* start, void* stop, float* ms) {
+    SBGM_HIP(hipEventSynchronize((hipEvent_t)stop));
+    SBGM_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return 0;
+}
+int sbgm_event_destroy(void* ev) { SBGM_HIP(hipEventDestroy((hipEvent_t)ev)); return 0; }
+
+}  // extern "C"

@@ -1,0 +1,111 @@
+// Internal launcher interface between the kernel translation units and the engine / C-ABI layer.
+// Every launcher enqueues on `st`, never synchronises and never allocates (graph-capture safe).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <algorithm>
+
+struct ConvGeom {
+    int kh, kw, stride, pad;
+};
+struct ConvTile {
+    int fco, fpx, splits;   // wave tile = (16*fco) output channels x (16*fpx) pixels; split-K factor
+};
+struct ConvParams {
+    const float* x;       // NHWC [B][H][W][Cs]
+    const float* wp;      // packed weights [nsteps][Cout][16]
+    float* out;           // NHWC [M][Cout]
+    const float* scale;   // [Cout] or null   (folded BatchNorm gamma/sqrt(var+eps))
+    const float* bias;    // [Cout] or null
+    const float* tbias;   // [B][Cout] or null (time-projection bias, broadcast over pixels)
+    const float* res;     // [M][Cout] or null (residual / skip)
+    int B, H, W, Cs, Cout;
+    int act, tbias_after_act;
+    // filled by sbgm_launch_conv:
+    int OH, OW, M, cb_per_tap, nsteps, steps_per_split, n_px_tiles, n_co_tiles;
+    uint32_t x_bytes, w_bytes;
+};
+
+int sbgm_conv_nsteps(int KH, int KW, int cs);
+int sbgm_launch_pack_conv_weight(const float* w_oihw, float* wp, int Cout, int Cin, int KH, int KW, int cs, hipStream_t st);
+int sbgm_launch_conv(const ConvGeom& g, ConvParams p, const ConvTile& cfg, float* partial_ws, hipStream_t st);
+
+// ---- pointwise.hip ---------------------------------------------------------------------------------
+struct PackSrc {
+    const float* ptr[4];   // NCHW sources, concatenated along C in this order
+    int ch[4];
+    int n;
+};
+int sbgm_launch_pack_input(const PackSrc& src, float* dst_nhwc, int B, int H, int W, int Cs, hipStream_t st);
+int sbgm_launch_nhwc_to_nchw(const float* src, float* dst, int B, int H, int W, int C, hipStream_t st);
+int sbgm_launch_nchw_to_nhwc(const float* src, float* dst, int B, int H, int W, int C, hipStream_t st);
+int sbgm_launch_upsample2x(const float* x, float* y, int B, int H, int W, int C, hipStream_t st);
+int sbgm_launch_act(float* x, size_t n, int act, hipStream_t st);
+int sbgm_launch_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                        float* scale, float* bias, int C, hipStream_t st);
+
+struct TimeProj {          // out[b][c] = bias[c] + sum_d W[c][d] * silu(emb_g[b][d])
+    const float* weight;   // [ch][D] (nn.Linear layout)
+    const float* bias;     // [ch]
+    float* out;            // [B][ch]
+    int ch;
+    int emb;               // which embedding (index into freqs[])
+};
+struct TimeEmbedArgs {
+    const float* t;             // [B]
+    const int64_t* y;           // [B] or null
+    const float* label_emb;     // [ncls+1][D] or null (added to embedding 0 only)
+    const float* freqs[8];      // Gaussian-Fourier W vectors [D/2]
+    int n_emb;
+    TimeProj proj[16];
+    int n_proj;
+    float* emb_ws;              // workspace [n_emb][B][D]: silu(embedding)
+    int B, D;
+};
+int sbgm_launch_time_embed(const TimeEmbedArgs& a, hipStream_t st);
+
+// final 3x3 conv with a single output channel, fused with the division by sigma(t): out NCHW [B,1,H,W]
+int sbgm_launch_conv3x3_cout1(const float* x, const float* w_tap_c, const float* bias, const float* t, float sigma,
+                              float* out, int B, int H, int W, int C, hipStream_t st);
+int sbgm_launch_pack_cout1_weight(const float* w_oihw, float* w_tap_c, int C, hipStream_t st);
+
+// ---- norm.hip ------------------------------------------------------------------------------------------
+// GroupNorm / InstanceNorm over NHWC.  stats_ws: 2*B*G doubles followed by 2*B*G floats (24 B per statistic;
+// for batchnorm B*G -> C).  Zeroed by the launcher.
+int sbgm_launch_groupnorm(const float* x, float* y, const float* gamma, const float* beta, const float* skip,
+                          const float* tbias, int act, int B, int HW, int C, int G, float eps, double* stats_ws,
+                          hipStream_t st);
+int sbgm_launch_layernorm(const float* x, float* y, const float* gamma, const float* beta, int M, int C, float eps,
+                          hipStream_t st);
+// train-mode BatchNorm2d: batch statistics over (B,H,W), running-stat update, optional residual + ReLU
+int sbgm_launch_batchnorm_train(const float* x, float* y, const float* gamma, const float* beta, float* running_mean,
+                                float* running_var, const float* res, const float* tbias_after, int relu, int B,
+                                int HW, int C, float eps, float momentum, double* stats_ws, hipStream_t st);
+
+// ---- attention.hip -------------------------------------------------------------------------------------
+int sbgm_launch_mha_core(const float* qkv, float* out, int B, int S, int C, int heads, hipStream_t st);
+
+// ---- sampler.hip ---------------------------------------------------------------------------------------
+struct StepScalars {       // one row of the device-side step table
+    float t;               // time fed to the network at this step
+    float g2;              // g(t)^2
+    float dt;              // step size
+    float noise;           // coefficient of the fresh N(0,1) draw in the predictor
+    float t_next;          // time of the next step (written to the device time vector after the update)
+};
+struct SamplerState {      // device-resident, lets one captured graph serve every step
+    unsigned long long step;        // advanced by the predictor kernel
+    unsigned long long rng_offset;  // Philox counter base, advanced by every noise-drawing kernel
+};
+int sbgm_launch_fill_t(float* t, float value, int B, hipStream_t st);
+// `state` != null: scalars / RNG offset come from device memory (graph-replayable) and the state is advanced after
+// the update; `state` == null: explicit by-value scalars and draw index.
+int sbgm_launch_init_noise(float* x, float scale, const float* z, unsigned long long seed, SamplerState* state,
+                           unsigned long long draw_index, size_t n, hipStream_t st);
+int sbgm_launch_em_update(float* x, float* x_mean, const float* score, const float* z, const StepScalars* table,
+                          SamplerState* state, const StepScalars* sc_val, unsigned long long draw_index, float* t_dev,
+                          unsigned long long seed, int B, size_t per_sample, int n_steps, hipStream_t st);
+int sbgm_launch_langevin(float* x, const float* score, const float* z, float snr_noise_norm, double* sumsq_ws,
+                         SamplerState* state, unsigned long long draw_index, unsigned long long seed, int B,
+                         size_t per_sample, hipStream_t st);
+int sbgm_launch_cfg_combine(float* out, const float* s_cond, const float* s_uncond, float scale, size_t n, hipStream_t st);

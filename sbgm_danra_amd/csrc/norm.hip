@@ -1,0 +1,242 @@
+// Normalisation kernels over NHWC fp32: GroupNorm/InstanceNorm (decoder), LayerNorm (attention tokens) and
+// train-mode BatchNorm2d (encoder).  All reductions: per-thread fp32 partials over short pixel stripes,
+// wavefront / LDS combination in fp64, one fp64 atomic per (workgroup, statistic).
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int NORM_THREADS = 256;
+
+// ---- statistics: sum and sum of squares per (sample, channel-set) ------------------------------------------
+// Grid (chunks, B).  Thread layout: channel quad fastest (coalesced 16 B loads along C), pixel stripes above.
+// `per_channel` = 0: reduce to G groups of C/G channels (GroupNorm);  = 1: keep C channels (BatchNorm, where
+// blockIdx.y slices pixels of the whole batch instead of one sample).
+template <bool PER_CHANNEL>
+__global__ __launch_bounds__(NORM_THREADS) void norm_stats_kernel(const float* __restrict__ x, double* __restrict__ stats,
+                                                                  int HW, int C, int G, int px_per_block) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* ssum = reinterpret_cast<double*>(smem_raw);   // [C]
+    double* ssq = ssum + C;                               // [C]
+    const int cq = C >> 2;
+    const int b = blockIdx.y;
+    for (int c = threadIdx.x; c < 2 * C; c += NORM_THREADS) ssum[c] = 0.0;
+    __syncthreads();
+
+    const int q = threadIdx.x % cq;
+    const int lanes_px = NORM_THREADS / cq;       // pixel stripes handled concurrently (cq <= 256)
+    const int stripe = threadIdx.x / cq;
+    const int p_begin = blockIdx.x * px_per_block;
+    const int p_end = min(HW, p_begin + px_per_block);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    if (stripe < lanes_px) {
+        const float* base = x + (size_t)b * HW * C + q * 4;
+        for (int p = p_begin + stripe; p < p_end; p += lanes_px) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)p * C);
+            s += v;
+            s2 += v * v;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            atomicAdd(&ssum[q * 4 + e], (double)s[e]);      // ds_add_f64
+            atomicAdd(&ssq[q * 4 + e], (double)s2[e]);
+        }
+    }
+    __syncthreads();
+    if (PER_CHANNEL) {
+        for (int c = threadIdx.x; c < C; c += NORM_THREADS) {
+            atomicAdd(&stats[2 * c], ssum[c]);
+            atomicAdd(&stats[2 * c + 1], ssq[c]);
+        }
+    } else {
+        const int cpg = C / G;
+        for (int g = threadIdx.x; g < G; g += NORM_THREADS) {
+            double a = 0.0, a2 = 0.0;
+            for (int c = g * cpg; c < (g + 1) * cpg; ++c) { a += ssum[c]; a2 += ssq[c]; }
+            atomicAdd(&stats[((size_t)b * G + g) * 2], a);
+            atomicAdd(&stats[((size_t)b * G + g) * 2 + 1], a2);
+        }
+    }
+}
+
+
+// sums -> (mean, rstd) as floats, once per statistic, so the streaming apply kernels stay HBM-bound
+__global__ void norm_finalize_kernel(const double* __restrict__ stats, float* __restrict__ mr, int n_stats, double inv_n,
+                                     float eps) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_stats) {
+        const double mean = stats[2 * i] * inv_n;
+        const double var = fmax(stats[2 * i + 1] * inv_n - mean * mean, 0.0);
+        mr[2 * i] = (float)mean;
+        mr[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+// ---- K18 + K21 + K12 + K20: y = act( GN(x) * gamma + beta  [+ skip] [+ tbias[b]] ) ---------------------------
+// reference score_unet.py:585/592 (norms), :600 (skip add), :612 (time add), :615 (activation)
+__global__ __launch_bounds__(256) void groupnorm_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta,
+                                                              const float* __restrict__ skip,
+                                                              const float* __restrict__ tbias, int act, int B, int HW,
+                                                              int C, int G, const float* __restrict__ mr) {
+    const int cq = C >> 2, cpg = C / G;
+    const size_t total = (size_t)B * HW * cq;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % cq);
+        const int b = (int)(i / ((size_t)cq * HW));
+        const int c = q * 4;
+        f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int g = (c + e) / cpg;
+            const float mean = mr[((size_t)b * G + g) * 2], rstd = mr[((size_t)b * G + g) * 2 + 1];
+            float o = (v[e] - mean) * rstd;
+            if (gamma) o = o * gamma[c + e] + beta[c + e];
+            v[e] = o;
+        }
+        if (skip) v += reinterpret_cast<const f32x4*>(skip)[i];
+        if (tbias) v += *reinterpret_cast<const f32x4*>(tbias + (size_t)b * C + c);
+        if (act != SBGM_ACT_NONE) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = sbgm_act(v[e], act);
+        }
+        reinterpret_cast<f32x4*>(y)[i] = v;
+    }
+}
+
+// ---- K13: LayerNorm over C, one wave per token, two-pass in registers (wavefront shuffle reductions) ----------
+// reference score_unet.py:128-129, :141, :145 (eps 1e-5, affine)
+template <int VPL>   // float4 vectors per lane: C = 256 * VPL  (VPL = 0 -> generic strided path)
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                        const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, int M, int C, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * C;
+    float* yr = y + (size_t)row * C;
+    float s = 0.f;
+    for (int c = lane * 4; c < C; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+        s += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    const float mean = wave_sum(s) / (float)C;
+    float s2 = 0.f;
+    for (int c = lane * 4; c < C; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c) - mean;
+        s2 += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    }
+    const float rstd = 1.f / sqrtf(wave_sum(s2) / (float)C + eps);
+    for (int c = lane * 4; c < C; c += 256) {
+        const f32x4 v = (*reinterpret_cast<const f32x4*>(xr + c) - mean) * rstd;
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c);
+        *reinterpret_cast<f32x4*>(yr + c) = v * g + be;
+    }
+}
+
+// ---- K10 (train): BatchNorm2d with batch statistics ---------------------------------------------------------
+// y = relu?( (x - mean_c) * rsqrt(var_c + eps) * gamma + beta [+ res] ) [+ tbias_after[b]];  running stats get
+// momentum-weighted mean and UNBIASED variance, as torch.nn.BatchNorm2d does (used at score_unet.py:323 and in
+// every BasicBlock).
+__global__ __launch_bounds__(256) void batchnorm_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ beta,
+                                                              const float* __restrict__ res,
+                                                              const float* __restrict__ tbias_after, int relu, int B,
+                                                              int HW, int C, const float* __restrict__ mr) {
+    const int cq = C >> 2;
+    const size_t total = (size_t)B * HW * cq;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cq) * 4;
+        const int b = (int)(i / ((size_t)cq * HW));
+        f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            v[e] = (v[e] - mr[2 * (c + e)]) * mr[2 * (c + e) + 1] * gamma[c + e] + beta[c + e];
+        }
+        if (res) v += reinterpret_cast<const f32x4*>(res)[i];
+        if (relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        if (tbias_after) v += *reinterpret_cast<const f32x4*>(tbias_after + (size_t)b * C + c);
+        reinterpret_cast<f32x4*>(y)[i] = v;
+    }
+}
+
+__global__ void batchnorm_running_kernel(float* running_mean, float* running_var, const double* stats, int C,
+                                         double n, float momentum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        const double mean = stats[2 * c] / n;
+        const double var = fmax(stats[2 * c + 1] / n - mean * mean, 0.0);
+        const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+inline int stream_blocks(size_t work_items) { return (int)std::min<size_t>((work_items + 255) / 256, 2048); }
+
+}  // namespace
+
+int sbgm_launch_groupnorm(const float* x, float* y, const float* gamma, const float* beta, const float* skip,
+                          const float* tbias, int act, int B, int HW, int C, int G, float eps, double* stats_ws,
+                          hipStream_t st) {
+    SBGM_CHECK(C % 4 == 0 && C <= 1024 && C % G == 0, "groupnorm: C=%d G=%d unsupported", C, G);
+    SBGM_CHECK((gamma == nullptr) == (beta == nullptr), "groupnorm: gamma and beta must both be set or both null");
+    SBGM_HIP(hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * (size_t)B * G, st));
+    // ~64 pixels per stripe-thread keeps the fp32 partials short; at least 1 chunk, at most 256 per sample
+    const int lanes_px = std::max(1, NORM_THREADS / (C / 4));
+    int chunks = std::max(1, std::min(256, HW / (lanes_px * 32)));
+    const int ppb = (HW + chunks - 1) / chunks;
+    chunks = (HW + ppb - 1) / ppb;
+    hipLaunchKernelGGL(norm_stats_kernel<false>, dim3(chunks, B), dim3(NORM_THREADS), 2 * C * sizeof(double), st, x,
+                       stats_ws, HW, C, G, ppb);
+    SBGM_LAUNCH_CHECK();
+    float* mr = reinterpret_cast<float*>(stats_ws + 2 * (size_t)B * G);
+    hipLaunchKernelGGL(norm_finalize_kernel, dim3((B * G + 255) / 256), dim3(256), 0, st, stats_ws, mr, B * G,
+                       1.0 / ((double)HW * (C / G)), eps);
+    SBGM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(stream_blocks((size_t)B * HW * (C / 4))), dim3(256), 0, st, x, y, gamma,
+                       beta, skip, tbias, act, B, HW, C, G, mr);
+    SBGM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sbgm_launch_layernorm(const float* x, float* y, const float* gamma, const float* beta, int M, int C, float eps,
+                          hipStream_t st) {
+    SBGM_CHECK(C % 4 == 0, "layernorm: C=%d must be a multiple of 4", C);
+    hipLaunchKernelGGL(layernorm_kernel<0>, dim3((M + 3) / 4), dim3(256), 0, st, x, y, gamma, beta, M, C, eps);
+    SBGM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sbgm_launch_batchnorm_train(const float* x, float* y, const float* gamma, const float* beta, float* running_mean,
+                                float* running_var, const float* res, const float* tbias_after, int relu, int B,
+                                int HW, int C, float eps, float momentum, double* stats_ws, hipStream_t st) {
+    SBGM_CHECK(C % 4 == 0 && C <= 1024, "batchnorm: C=%d unsupported", C);
+    SBGM_HIP(hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * (size_t)C, st));
+    // treat the batch as one long pixel axis: [B*HW][C]
+    const int n = B * HW;
+    const int lanes_px = std::max(1, NORM_THREADS / (C / 4));
+    int chunks = std::max(1, std::min(1024, n / (lanes_px * 32)));
+    const int ppb = (n + chunks - 1) / chunks;
+    chunks = (n + ppb - 1) / ppb;
+    hipLaunchKernelGGL(norm_stats_kernel<true>, dim3(chunks, 1), dim3(NORM_THREADS), 2 * C * sizeof(double), st, x,
+                       stats_ws, n, C, 1, ppb);
+    SBGM_LAUNCH_CHECK();
+    float* mr = reinterpret_cast<float*>(stats_ws + 2 * (size_t)C);
+    hipLaunchKernelGGL(norm_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, stats_ws, mr, C, 1.0 / (double)n, eps);
+    SBGM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(batchnorm_apply_kernel, dim3(stream_blocks((size_t)n * (C / 4))), dim3(256), 0, st, x, y, gamma, beta,
+                       res, tbias_after, relu, B, HW, C, mr);
+    SBGM_LAUNCH_CHECK();
+    if (running_mean != nullptr) {
+        hipLaunchKernelGGL(batchnorm_running_kernel, dim3((C + 255) / 256), dim3(256), 0, st, running_mean, running_var,
+                           stats_ws, C, (double)n, momentum);
+        SBGM_LAUNCH_CHECK();
+    }
+    return 0;
+}

@@ -1,0 +1,295 @@
+// Streaming (HBM-bound) kernels around the convolutions: layout packing, bilinear x2 upsample, BatchNorm
+// folding, the Gaussian-Fourier time embedding + time projections, and the single-output-channel final conv.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+// ---- K4: channel concat + NCHW -> NHWC (zero-padded to Cs channels) --------------------------------------
+// reference sbgm/score_unet.py:273-291 (torch.cat of x, lsm, topo, cond_img along C)
+// One thread per (pixel, channel-quad); reads are coalesced along W per source plane, writes are 16 B.
+__global__ __launch_bounds__(256) void pack_input_kernel(PackSrc src, float* __restrict__ dst, int B, int HW, int Cs) {
+    const int cq = Cs >> 2;
+    const size_t total = (size_t)B * HW * cq;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % cq);
+        const size_t pix = i / cq;            // b*HW + p
+        const int b = (int)(pix / HW);
+        const int p = (int)(pix - (size_t)b * HW);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            int c = q * 4 + e;
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (s < src.n) {
+                    if (c >= 0 && c < src.ch[s]) v[e] = src.ptr[s][((size_t)b * src.ch[s] + c) * HW + p];
+                    c -= src.ch[s];
+                }
+            }
+        }
+        *reinterpret_cast<f32x4*>(dst + pix * Cs + q * 4) = v;
+    }
+}
+
+// Tiled transposes between NCHW and NHWC through LDS (32 pixels x 32 channels per tile, +1 padding).
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                            int HW, int C) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, p = p0 + tx;
+        tile[r][tx] = (c < C && p < HW) ? src[((size_t)b * C + c) * HW + p] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int p = p0 + r, c = c0 + tx;
+        if (c < C && p < HW) dst[((size_t)b * HW + p) * C + c] = tile[tx][r];
+    }
+}
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                            int HW, int C) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z, p0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int p = p0 + r, c = c0 + tx;
+        tile[r][tx] = (c < C && p < HW) ? src[((size_t)b * HW + p) * C + c] : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int c = c0 + r, p = p0 + tx;
+        if (c < C && p < HW) dst[((size_t)b * C + c) * HW + p] = tile[tx][r];
+    }
+}
+
+// ---- K16: bilinear x2, align_corners=False (nn.Upsample, reference score_unet.py:467,583) ------------
+// out(2i)   = .25*in(i-1) + .75*in(i)   (i=0: in(0));   out(2i+1) = .75*in(i) + .25*in(i+1)  (clamped)
+// evaluated as PyTorch does: w0h*(w0w*v00 + w1w*v01) + w1h*(w0w*v10 + w1w*v11).
+__global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict__ x, float* __restrict__ y, int B,
+                                                         int H, int W, int C) {
+    const int cq = C >> 2, OH = 2 * H, OW = 2 * W;
+    const size_t total = (size_t)B * OH * OW * cq;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % cq);
+        size_t r = i / cq;
+        const int ox = (int)(r % OW); r /= OW;
+        const int oy = (int)(r % OH);
+        const int b = (int)(r / OH);
+        // source index = max(0, (o + 0.5) * 0.5 - 0.5)
+        const float sy = fmaxf(0.f, (oy + 0.5f) * 0.5f - 0.5f), sx = fmaxf(0.f, (ox + 0.5f) * 0.5f - 0.5f);
+        const int y0 = (int)sy, x0 = (int)sx;
+        const int y1 = min(y0 + 1, H - 1), x1 = min(x0 + 1, W - 1);
+        const float ly = sy - (float)y0, lx = sx - (float)x0;
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        const float* base = x + (size_t)b * H * W * C + q * 4;
+        const f32x4 v00 = *reinterpret_cast<const f32x4*>(base + ((size_t)y0 * W + x0) * C);
+        const f32x4 v01 = *reinterpret_cast<const f32x4*>(base + ((size_t)y0 * W + x1) * C);
+        const f32x4 v10 = *reinterpret_cast<const f32x4*>(base + ((size_t)y1 * W + x0) * C);
+        const f32x4 v11 = *reinterpret_cast<const f32x4*>(base + ((size_t)y1 * W + x1) * C);
+        const f32x4 o = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+        *reinterpret_cast<f32x4*>(y + i * 4) = o;
+    }
+}
+
+// ---- K10 (eval): fold BatchNorm2d running statistics into a per-channel scale / bias ------------------
+__global__ void bn_fold_kernel(const float* g, const float* be, const float* mu, const float* var, float eps,
+                               float* scale, float* bias, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) {
+        const float s = g[c] / sqrtf(var[c] + eps);
+        scale[c] = s;
+        bias[c] = be[c] - mu[c] * s;
+    }
+}
+
+// ---- K1 + K3: Gaussian-Fourier features, optional label-embedding add, SiLU ----------------------------
+// reference score_unet.py:41-45 (x*W*2pi in that association), :301-308, and the SiLU that opens every
+// time-projection nn.Sequential (:377-381, :501-504).  sinf/cosf are the full-range-reduction versions
+// (|2 pi t W| reaches several hundred): never compile this file with fast-math.
+__global__ __launch_bounds__(256) void time_embed_kernel(TimeEmbedArgs a) {
+    const int half = a.D >> 1;
+    const int total = a.n_emb * a.B * a.D;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int d = i % a.D;
+        const int b = (i / a.D) % a.B;
+        const int g = i / (a.D * a.B);
+        const float w = a.freqs[g][d < half ? d : d - half];
+        const float proj = (a.t[b] * w) * 6.283185307179586f;
+        float e = d < half ? sinf(proj) : cosf(proj);
+        if (g == 0 && a.y != nullptr) e += a.label_emb[(size_t)a.y[b] * a.D + d];
+        a.emb_ws[i] = e / (1.f + expf(-e));
+    }
+}
+
+// ---- K2: all time projections of one forward in one launch; one wave per output element --------------
+__global__ __launch_bounds__(256) void time_proj_kernel(TimeEmbedArgs a, int total_out) {
+    const int lane = threadIdx.x & 63;
+    const int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (wid >= total_out) return;
+    int rem = wid, pi = 0;
+    for (; pi < a.n_proj; ++pi) {
+        const int n = a.B * a.proj[pi].ch;
+        if (rem < n) break;
+        rem -= n;
+    }
+    const TimeProj& pr = a.proj[pi];
+    const int b = rem / pr.ch, c = rem - b * pr.ch;
+    const float* e = a.emb_ws + ((size_t)pr.emb * a.B + b) * a.D;
+    const float* w = pr.weight + (size_t)c * a.D;
+    float s = 0.f;
+    for (int d = lane; d < a.D; d += 64) s = fmaf(w[d], e[d], s);
+    s = wave_sum(s);
+    if (lane == 0) pr.out[(size_t)b * pr.ch + c] = s + pr.bias[c];
+}
+
+// ---- K19(final) + K22: 3x3, pad 1, C -> 1 output channel, then divide by sigma(t) ------------------------
+// reference score_unet.py:489 (final_layer.conv), :876-877 and marginal_prob_std :881-897.
+// HBM-bound: 16 lanes share one output pixel, each owns a float4 channel slice per tap (C = 64 -> one slice).
+__global__ __launch_bounds__(256) void conv3x3_cout1_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ bias, const float* __restrict__ t,
+                                                            float sigma, float* __restrict__ out, int B, int H, int W,
+                                                            int C) {
+    const int sub = threadIdx.x & 15;
+    const size_t npix = (size_t)B * H * W;
+    const size_t gstride = (size_t)gridDim.x * (blockDim.x >> 4);
+    for (size_t pix = (size_t)blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);; pix += gstride) {
+        // all 16 lanes of a group share `pix`; whole waves leave together only when every group is done
+        const bool live = pix < npix;
+        if (__all(!live)) break;
+        float acc = 0.f;
+        int b = 0;
+        if (live) {
+            const int ox = (int)(pix % W);
+            const int oy = (int)((pix / W) % H);
+            b = (int)(pix / ((size_t)W * H));
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int iy = oy + kh - 1;
+                if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const int ix = ox + kw - 1;
+                    if ((unsigned)ix >= (unsigned)W) continue;
+                    const float* xp = x + (((size_t)b * H + iy) * W + ix) * C;
+                    const float* wp = w + (kh * 3 + kw) * C;
+                    for (int c = sub * 4; c < C; c += 64) {
+                        const f32x4 xv = *reinterpret_cast<const f32x4*>(xp + c);
+                        const f32x4 wv = *reinterpret_cast<const f32x4*>(wp + c);
+                        acc = fmaf(xv[0], wv[0], acc);
+                        acc = fmaf(xv[1], wv[1], acc);
+                        acc = fmaf(xv[2], wv[2], acc);
+                        acc = fmaf(xv[3], wv[3], acc);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (live && sub == 0) {
+            float v = acc + bias[0];
+            if (t != nullptr) {
+                const float ls = logf(sigma);
+                const float var = (expf((2.f * t[b]) * ls) - 1.f) / (2.f * ls);
+                v /= fmaxf(sqrtf(var), 1e-5f);
+            }
+            out[pix] = v;
+        }
+    }
+}
+
+__global__ void pack_cout1_weight_kernel(const float* w, float* wp, int C) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;   // wp[tap][c] = w[0][c][kh][kw]
+    if (i < 9 * C) {
+        const int tap = i / C, c = i - tap * C;
+        wp[i] = w[c * 9 + tap];
+    }
+}
+
+__global__ __launch_bounds__(256) void act_kernel(float* x, size_t n4, int act) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        f32x4 v = reinterpret_cast<f32x4*>(x)[i];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = sbgm_act(v[e], act);
+        reinterpret_cast<f32x4*>(x)[i] = v;
+    }
+}
+
+inline int stream_blocks(size_t work_items) { return (int)std::min<size_t>((work_items + 255) / 256, 2048); }
+
+}  // namespace
+
+int sbgm_launch_pack_input(const PackSrc& src, float* dst, int B, int H, int W, int Cs, hipStream_t st) {
+    int ctot = 0;
+    for (int i = 0; i < src.n; ++i) ctot += src.ch[i];
+    SBGM_CHECK(src.n >= 1 && src.n <= 4, "pack_input: %d sources (1..4 supported)", src.n);
+    SBGM_CHECK(Cs % 4 == 0 && ctot <= Cs, "pack_input: %d channels do not fit padded width %d", ctot, Cs);
+    hipLaunchKernelGGL(pack_input_kernel, dim3(stream_blocks((size_t)B * H * W * (Cs / 4))), dim3(256), 0, st, src, dst, B,
+                       H * W, Cs);
+    SBGM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sbgm_launch_nchw_to_nhwc(const float* src, float* dst, int B, int H, int W, int C, hipStream_t st) {
+    dim3 grid((H * W + 31) / 32, (C + 31) / 32, B);
+    hipLaunchKernelGGL(nchw_to_nhwc_kernel, grid, dim3(256), 0, st, src, dst, H * W, C);
+    SBGM_LAUNCH_CHECK();
+    return 0;
+}
+int sbgm_launch_nhwc_to_nchw(const float* src, float* dst, int B, int H, int W, int C, hipStream_t st) {
+    dim3 grid((H * W + 31) / 32, (C + 31) / 32, B);
+    hipLaunchKernelGGL(nhwc_to_nchw_kernel, grid, dim3(256), 0, st, src, dst, H * W, C);
+    SBGM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sbgm_launch_upsample2x(const float* x, float* y, int B, int H, int W, int C, hipStream_t st) {
+    SBGM_CHECK(C % 4 == 0, "upsample2x: C=%d must be a multiple of 4", C);
+    hipLaunchKernelGGL(upsample2x_kernel, dim3(stream_blocks((size_t)B * H * W * C)), dim3(256), 0, st, x, y, B, H, W, C);
+    SBGM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sbgm_launch_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                        float* scale, float* bias, int C, hipStream_t st) {
+    hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, st, gamma, beta, mean, var, eps, scale, bias, C);
+    SBGM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sbgm_launch_time_embed(const TimeEmbedArgs& a, hipStream_t st) {
+    SBGM_CHECK(a.n_emb >= 1 && a.n_emb <= 8 && a.n_proj >= 1 && a.n_proj <= 16, "time_embed: bad counts");
+    SBGM_CHECK(a.D % 2 == 0, "time_embed: D=%d must be even", a.D);
+    const int total = a.n_emb * a.B * a.D;
+    hipLaunchKernelGGL(time_embed_kernel, dim3((total + 255) / 256), dim3(256), 0, st, a);
+    SBGM_LAUNCH_CHECK();
+    int total_out = 0;
+    for (int i = 0; i < a.n_proj; ++i) total_out += a.B * a.proj[i].ch;
+    hipLaunchKernelGGL(time_proj_kernel, dim3((total_out + 3) / 4), dim3(256), 0, st, a, total_out);
+    SBGM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sbgm_launch_conv3x3_cout1(const float* x, const float* w_tap_c, const float* bias, const float* t, float sigma,
+                              float* out, int B, int H, int W, int C, hipStream_t st) {
+    SBGM_CHECK(C % 4 == 0, "conv3x3_cout1: C=%d must be a multiple of 4", C);
+    const size_t npix = (size_t)B * H * W;
+    hipLaunchKernelGGL(conv3x3_cout1_kernel, dim3((int)std::min<size_t>((npix + 15) / 16, 4096)), dim3(256), 0, st, x,
+                       w_tap_c, bias, t, sigma, out, B, H, W, C);
+    SBGM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sbgm_launch_pack_cout1_weight(const float* w_oihw, float* w_tap_c, int C, hipStream_t st) {
+    hipLaunchKernelGGL(pack_cout1_weight_kernel, dim3((9 * C + 255) / 256), dim3(256), 0, st, w_oihw, w_tap_c, C);
+    SBGM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sbgm_launch_act(float* x, size_t n, int act, hipStream_t st) {
+    SBGM_CHECK(n % 4 == 0, "act: n must be a multiple of 4");
+    hipLaunchKernelGGL(act_kernel, dim3(stream_blocks(n / 4)), dim3(256), 0, st, x, n / 4, act);
+    SBGM_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,203 @@
+// K25 / K26 / K27: per-step state updates of the reverse-SDE samplers, fused with the Gaussian draw.
+// reference sbgm/score_sampling.py:124-125 (Euler-Maruyama), :200-204 (Langevin corrector), :224-227 (predictor),
+// :55 (classifier-free-guidance combine).
+//
+// Noise: when `z` is null the kernels draw N(0,1) themselves (Philox4x32-10 counter RNG + Box-Muller, keyed by
+// (seed, running offset, element index)), so the sampler loop never round-trips noise through HBM; when `z`
+// is given (parity mode) the host-generated draw is used verbatim.
+// All per-step scalars come from a device-resident table indexed by a device-side step counter, so one captured
+// hipGraph replays for every step.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    c[1] = (uint32_t)p1;
+    c[3] = (uint32_t)p0;
+    c[0] = n0;
+    c[2] = n2;
+}
+
+// 4 standard normals for (seed, stream offset, index)
+__device__ __forceinline__ f32x4 philox_normal4(unsigned long long seed, unsigned long long offset, unsigned long long idx) {
+    uint32_t c[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)offset, (uint32_t)(offset >> 32)};
+    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philox_round(c, k0, k1);
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    const float u0 = ((float)(c[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);   // (0,1)
+    const float u1 = ((float)(c[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u2 = ((float)(c[2] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float u3 = ((float)(c[3] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float r0 = sqrtf(-2.f * logf(u0)), r1 = sqrtf(-2.f * logf(u2));
+    float s0, c0, s1, c1;
+    sincosf(6.283185307179586f * u1, &s0, &c0);
+    sincosf(6.283185307179586f * u3, &s1, &c1);
+    return f32x4{r0 * c0, r0 * s0, r1 * c1, r1 * s1};
+}
+
+__global__ void fill_kernel(float* t, float v, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) t[i] = v;
+}
+
+// x = scale * N(0,1)   (sampler start: randn * marginal_prob_std(1), score_sampling.py:94-95, :168)
+__global__ __launch_bounds__(256) void init_noise_kernel(float* __restrict__ x, float scale, const float* __restrict__ z,
+                                                         unsigned long long seed, const SamplerState* __restrict__ state,
+                                                         unsigned long long off_val, size_t n4) {
+    const unsigned long long off = state ? state->rng_offset : off_val;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 n = z ? reinterpret_cast<const f32x4*>(z)[i] : philox_normal4(seed, off, i);
+        reinterpret_cast<f32x4*>(x)[i] = n * scale;
+    }
+}
+
+// x_mean = x + g^2 dt * score ;  x = x_mean + noise_coef * N(0,1)
+__global__ __launch_bounds__(256) void em_update_kernel(float* __restrict__ x, float* __restrict__ x_mean,
+                                                        const float* __restrict__ score, const float* __restrict__ z,
+                                                        const StepScalars* __restrict__ table,
+                                                        const SamplerState* __restrict__ state, StepScalars sc_val,
+                                                        unsigned long long off_val, unsigned long long seed, size_t n4) {
+    const StepScalars sc = state ? table[state->step] : sc_val;
+    const unsigned long long off = state ? state->rng_offset : off_val;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
+        const f32x4 sv = reinterpret_cast<const f32x4*>(score)[i];
+        const f32x4 n = z ? reinterpret_cast<const f32x4*>(z)[i] : philox_normal4(seed, off, i);
+        const f32x4 mean = xv + (sc.g2 * sv) * sc.dt;   // association of score_sampling.py:124/:224
+        reinterpret_cast<f32x4*>(x_mean)[i] = mean;
+        reinterpret_cast<f32x4*>(x)[i] = mean + sc.noise * n;
+    }
+}
+
+// runs after the update kernel of a step: advance the step counter / RNG offset, publish the next time
+__global__ void advance_kernel(SamplerState* state, const StepScalars* table, float* t_dev, int B, int advance_step,
+                               int n_steps) {
+    const unsigned long long s = state->step;
+    const int i = threadIdx.x;
+    if (advance_step && t_dev && i < B) t_dev[i] = table[s].t_next;
+    __syncthreads();
+    if (i == 0) {
+        state->rng_offset += 1;
+        if (advance_step) state->step = (s + 1 < (unsigned long long)n_steps) ? s + 1 : s;
+    }
+}
+
+// per-sample sum of squares of the score, fp64 atomics into sumsq[B] (zeroed by the launcher)
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ score, double* __restrict__ sumsq,
+                                                    size_t per_sample4) {
+    const int b = blockIdx.y;
+    const f32x4* s = reinterpret_cast<const f32x4*>(score) + (size_t)b * per_sample4;
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_sample4; i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 v = s[i];
+        acc += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+    }
+    const double w = wave_sum_d((double)acc);
+    if ((threadIdx.x & 63) == 0) atomicAdd(&sumsq[b], w);
+}
+
+// Langevin corrector: eps = 2 (snr*sqrt(CHW) / mean_b ||score_b||)^2 ;  x += eps*score + sqrt(2 eps) N(0,1)
+__global__ __launch_bounds__(256) void langevin_kernel(float* __restrict__ x, const float* __restrict__ score,
+                                                       const float* __restrict__ z, float snr_noise_norm,
+                                                       const double* __restrict__ sumsq,
+                                                       const SamplerState* __restrict__ state,
+                                                       unsigned long long off_val, unsigned long long seed, int B,
+                                                       size_t n4) {
+    float gn = 0.f;
+    for (int b = 0; b < B; ++b) gn += (float)sqrt(sumsq[b]);
+    gn /= (float)B;
+    const float r = snr_noise_norm / gn;
+    const float eps = 2.f * (r * r);
+    const float nz = sqrtf(2.f * eps);
+    const unsigned long long off = state ? state->rng_offset : off_val;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
+        const f32x4 sv = reinterpret_cast<const f32x4*>(score)[i];
+        const f32x4 n = z ? reinterpret_cast<const f32x4*>(z)[i] : philox_normal4(seed, off, i);
+        reinterpret_cast<f32x4*>(x)[i] = xv + eps * sv + nz * n;
+    }
+}
+
+__global__ __launch_bounds__(256) void cfg_combine_kernel(float* __restrict__ out, const float* __restrict__ sc,
+                                                          const float* __restrict__ su, float w, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(sc)[i], b = reinterpret_cast<const f32x4*>(su)[i];
+        reinterpret_cast<f32x4*>(out)[i] = (1.0f + w) * a - w * b;
+    }
+}
+
+inline int stream_blocks(size_t n) { return (int)std::min<size_t>((n + 255) / 256, 2048); }
+
+}  // namespace
+
+int sbgm_launch_fill_t(float* t, float value, int B, hipStream_t st) {
+    hipLaunchKernelGGL(fill_kernel, dim3((B + 255) / 256), dim3(256), 0, st, t, value, B);
+    SBGM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sbgm_launch_init_noise(float* x, float scale, const float* z, unsigned long long seed, SamplerState* state,
+                           unsigned long long draw_index, size_t n, hipStream_t st) {
+    SBGM_CHECK(n % 4 == 0, "init_noise: element count must be a multiple of 4");
+    hipLaunchKernelGGL(init_noise_kernel, dim3(stream_blocks(n / 4)), dim3(256), 0, st, x, scale, z, seed, state, draw_index,
+                       n / 4);
+    SBGM_LAUNCH_CHECK();
+    if (state) {
+        hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(64), 0, st, state, (const StepScalars*)nullptr, (float*)nullptr, 0, 0, 0);
+        SBGM_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+int sbgm_launch_em_update(float* x, float* x_mean, const float* score, const float* z, const StepScalars* table,
+                          SamplerState* state, const StepScalars* sc_val, unsigned long long draw_index, float* t_dev,
+                          unsigned long long seed, int B, size_t per_sample, int n_steps, hipStream_t st) {
+    const size_t n = (size_t)B * per_sample;
+    SBGM_CHECK(n % 4 == 0, "em_update: element count must be a multiple of 4");
+    SBGM_CHECK(B <= 1024, "em_update: batch %d > 1024", B);
+    SBGM_CHECK(state != nullptr || sc_val != nullptr, "em_update: need a device table or explicit scalars");
+    const StepScalars v = sc_val ? *sc_val : StepScalars{};
+    hipLaunchKernelGGL(em_update_kernel, dim3(stream_blocks(n / 4)), dim3(256), 0, st, x, x_mean, score, z, table, state, v,
+                       draw_index, seed, n / 4);
+    SBGM_LAUNCH_CHECK();
+    if (state) {
+        hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1024), 0, st, state, table, t_dev, B, 1, n_steps);
+        SBGM_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+int sbgm_launch_langevin(float* x, const float* score, const float* z, float snr_noise_norm, double* sumsq_ws,
+                         SamplerState* state, unsigned long long draw_index, unsigned long long seed, int B,
+                         size_t per_sample, hipStream_t st) {
+    SBGM_CHECK(per_sample % 4 == 0, "langevin: per-sample element count must be a multiple of 4");
+    SBGM_HIP(hipMemsetAsync(sumsq_ws, 0, sizeof(double) * B, st));
+    const int bx = (int)std::min<size_t>((per_sample / 4 + 255) / 256, 64);
+    hipLaunchKernelGGL(sumsq_kernel, dim3(bx, B), dim3(256), 0, st, score, sumsq_ws, per_sample / 4);
+    SBGM_LAUNCH_CHECK();
+    const size_t n4 = (size_t)B * per_sample / 4;
+    hipLaunchKernelGGL(langevin_kernel, dim3(stream_blocks(n4)), dim3(256), 0, st, x, score, z, snr_noise_norm, sumsq_ws,
+                       state, draw_index, seed, B, n4);
+    SBGM_LAUNCH_CHECK();
+    if (state) {
+        hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(64), 0, st, state, (const StepScalars*)nullptr, (float*)nullptr, 0, 0, 0);
+        SBGM_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+int sbgm_launch_cfg_combine(float* out, const float* s_cond, const float* s_uncond, float scale, size_t n, hipStream_t st) {
+    SBGM_CHECK(n % 4 == 0, "cfg_combine: element count must be a multiple of 4");
+    hipLaunchKernelGGL(cfg_combine_kernel, dim3(stream_blocks(n / 4)), dim3(256), 0, st, out, s_cond, s_uncond, scale, n / 4);
+    SBGM_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,390 @@
+"""Drop-in mirror of the reference's `sbgm/score_unet.py` public surface, with the bodies running on
+libsbgm_hip.so (hand-written gfx950 kernels) instead of torch.nn ops.
+
+Kept identical to the reference: class names, constructor signatures, `state_dict()` keys / shapes / layouts
+(OIHW convs, packed `mha.in_proj_weight`, BatchNorm buffers, the six Gaussian-Fourier `W` buffers), the call
+signature `ScoreNet.forward(x, t, y=None, cond_img=None, lsm_cond=None, topo_cond=None)`, NCHW fp32 tensors at
+the boundary and the exceptions raised for malformed input (reference score_unet.py:274-280, :596-597, :965-967).
+
+The torch.nn sub-modules below are parameter CONTAINERS only (so `load_state_dict`, `.to()`, `.parameters()`,
+optimizers and checkpoints behave exactly as in the reference); their own `forward` is never called.  The
+arithmetic happens in the native engine, which repacks the weights to NHWC / K-major on upload and is refreshed
+whenever a parameter's version counter changes.  There is no CPU fallback: a CPU tensor or a missing
+libsbgm_hip.so raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import functools
+import logging
+from typing import Iterable, Optional
+
+import torch
+import torch.nn as nn
+
+from . import _native as N
+
+logger = logging.getLogger(__name__)
+
+FMAP_CHANNELS = [64, 64, 128, 256, 512]          # reference score_unet.py:198
+
+
+# --------------------------------------------------------------------------------------------------------------
+# parameter containers (same attribute names as the reference / torchvision -> same state_dict keys)
+# --------------------------------------------------------------------------------------------------------------
+class _NativeOnly(nn.Module):
+    """Sub-modules hold parameters; evaluation goes through ScoreNet (whole-network engine)."""
+
+    def forward(self, *a, **k):
+        raise NotImplementedError(
+            f"{type(self).__name__} is evaluated by the native engine through ScoreNet.forward(); "
+            "stand-alone sub-module calls are not part of the accelerated path")
+
+
+class SinusoidalEmbedding(_NativeOnly):
+    """Gaussian-Fourier time features; container for the fixed `W` buffer (reference score_unet.py:24-45)."""
+
+    def __init__(self, embed_dim: int, scale: float = 30.0, device=None, dtype=torch.float32):
+        super().__init__()
+        if embed_dim % 2 != 0:
+            raise ValueError(f"Embedding dimension must be even, got {embed_dim}.")
+        self.register_buffer("W", torch.randn(embed_dim // 2, dtype=dtype, device=device) * scale, persistent=True)
+
+
+class ImageSelfAttention(_NativeOnly):
+    """Pre-LN residual MHA + FF over H*W tokens (reference score_unet.py:112-148)."""
+
+    def __init__(self, input_channels: int, n_heads: int, dropout: float = 0.0):
+        super().__init__()
+        if input_channels % n_heads != 0:
+            raise ValueError(f"Number of input channels ({input_channels}) must be divisible by number of heads ({n_heads}).")
+        if dropout != 0.0:
+            raise NotImplementedError("attention dropout is 0 on the reference path (score_unet.py:127)")
+        self.input_channels, self.n_heads = input_channels, n_heads
+        self.mha = nn.MultiheadAttention(embed_dim=input_channels, num_heads=n_heads, dropout=dropout, batch_first=True)
+        self.ln1 = nn.LayerNorm(input_channels)
+        self.ln2 = nn.LayerNorm(input_channels)
+        self.ff = nn.Sequential(nn.Linear(input_channels, input_channels), nn.GELU(),
+                                nn.Linear(input_channels, input_channels))
+
+
+class BasicBlock(_NativeOnly):
+    """torchvision ResNet basic block layout: conv1/bn1/relu/conv2/bn2/downsample."""
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride, 1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.relu = nn.ReLU(inplace=True)
+        self.conv2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.downsample = downsample
+        self.stride = stride
+
+
+class Encoder(_NativeOnly):
+    """ResNet-18-style encoder: two 8x8/s2 stem convs, 4 stages, time-bias adds, attention on the two deepest maps
+    (reference score_unet.py:151-404; stage layout from torchvision ResNet._make_layer)."""
+
+    def __init__(self, input_channels: int, time_embedding: int, block=BasicBlock, block_layers: list = [2, 2, 2, 2],
+                 n_heads: int = 4, num_classes: Optional[int] = None, cond_on_img=False, cond_img_dim=None, device=None):
+        super().__init__()
+        self.block, self.block_layers = block, list(block_layers)
+        self.time_embedding = time_embedding
+        self.input_channels = input_channels + 1          # + the noised HR field (reference :182)
+        self.n_heads, self.num_classes = n_heads, num_classes
+        self.device = device or torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        if len(self.block_layers) != 4:
+            raise ValueError("block_layers must have 4 entries (ResNet stages)")
+        self.conv1 = nn.Conv2d(self.input_channels, 64, kernel_size=(8, 8), stride=(2, 2), padding=(3, 3), bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        inplanes = 64
+        for li, (planes, nblocks) in enumerate(zip(FMAP_CHANNELS[1:], self.block_layers), start=1):
+            stride = 1 if li == 1 else 2
+            blocks = []
+            for bi in range(nblocks):
+                ds = None
+                if bi == 0 and (stride != 1 or inplanes != planes):
+                    ds = nn.Sequential(nn.Conv2d(inplanes, planes, 1, stride, bias=False), nn.BatchNorm2d(planes))
+                blocks.append(BasicBlock(inplanes, planes, stride if bi == 0 else 1, ds))
+                inplanes = planes
+            setattr(self, f"layer{li}", nn.Sequential(*blocks))
+        # torchvision init (Kaiming fan_out for convs, BN gamma=1 beta=0)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                nn.init.kaiming_normal_(m.weight, mode="fan_out", nonlinearity="relu")
+        self.sinusoidal_embedding = SinusoidalEmbedding(time_embedding)
+        self.time_projection_layers = self.make_time_projections(FMAP_CHANNELS)
+        self.attention_layers = self.make_attention_layers(FMAP_CHANNELS)
+        self.conv2 = nn.Conv2d(64, 64, kernel_size=(8, 8), stride=(2, 2), padding=(3, 3), bias=False)
+        if num_classes is not None:
+            self.label_emb = nn.Embedding(num_classes + 1, time_embedding)
+            with torch.no_grad():
+                self.label_emb.weight[0].fill_(0.0)       # null class (reference :224-226)
+
+    def make_time_projections(self, fmap_channels: Iterable[int]):
+        return nn.ModuleList([nn.Sequential(nn.SiLU(), nn.Linear(self.time_embedding, ch)) for ch in fmap_channels])
+
+    def make_attention_layers(self, fmap_channels: Iterable[int]):
+        fmap_channels = list(fmap_channels)
+        return nn.ModuleList([ImageSelfAttention(ch, self.n_heads) if i >= len(fmap_channels) - 2 else nn.Identity()
+                              for i, ch in enumerate(fmap_channels)])
+
+
+class DecoderBlock(_NativeOnly):
+    """upsample -> conv_up -> norm -> conv -> norm -> +skip -> +time -> act -> [attention]
+    (reference score_unet.py:409-627)."""
+
+    def __init__(self, input_channels: int, output_channels: int, time_embedding: int, upsample_scale: int = 2,
+                 activation: type = nn.ReLU, compute_attn: bool = True, n_heads: int = 4, device=None, *,
+                 use_resize_conv: bool = True, norm: str = "instance", gn_groups: int = 8):
+        super().__init__()
+        self.device = device or torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.input_channels, self.output_channels = input_channels, output_channels
+        self.upsample_scale, self.time_embedding = upsample_scale, time_embedding
+        self.compute_attn, self.n_heads = compute_attn, n_heads
+        self.use_resize_conv, self.norm_kind, self.gn_groups = use_resize_conv, norm, gn_groups
+        if upsample_scale != 2:
+            raise NotImplementedError("only the reference's x2 decoder upsampling is implemented")
+        if use_resize_conv:
+            self.upsample = nn.Upsample(scale_factor=upsample_scale, mode="bilinear", align_corners=False)
+            self.conv_up = nn.Conv2d(input_channels, input_channels, kernel_size=3, padding=1, bias=True)
+        else:
+            # ablation path of the reference (score_unet.py:470-475); parameters are kept so checkpoints load,
+            # but the native engine only implements the default resize-conv path.
+            self.transpose = nn.ConvTranspose2d(input_channels, input_channels, kernel_size=upsample_scale,
+                                                stride=upsample_scale)
+
+        def make_norm(c):
+            if self.norm_kind == "group":
+                return nn.GroupNorm(num_groups=max(1, min(gn_groups, c)), num_channels=c)
+            return nn.InstanceNorm2d(c)
+        self.norm1 = make_norm(input_channels)
+        self.conv = nn.Conv2d(input_channels, output_channels, kernel_size=3, padding=1)
+        self.norm2 = make_norm(output_channels)
+        self.activation = activation()
+        self.sinusoidal_embedding = SinusoidalEmbedding(time_embedding)
+        self.time_projection_layer = nn.Sequential(nn.SiLU(), nn.Linear(time_embedding, output_channels))
+        self.attention = ImageSelfAttention(output_channels, n_heads) if compute_attn else nn.Identity()
+
+
+class Decoder(_NativeOnly):
+    """Four DecoderBlocks (attention on the first two) and a norm-free, activation-free final block
+    (reference score_unet.py:662-789)."""
+
+    def __init__(self, last_fmap_channels: int, output_channels: int, time_embedding: int, first_fmap_channels: int = 64,
+                 n_heads: int = 4, device=None, *, use_resize_conv: bool = True, norm: str = "instance",
+                 gn_groups: int = 8, activation: type = nn.ReLU):
+        super().__init__()
+        self.device = device or torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.last_fmap_channels, self.output_channels = last_fmap_channels, output_channels
+        self.time_embedding, self.first_fmap_channels, self.n_heads = time_embedding, first_fmap_channels, n_heads
+        self.use_resize_conv, self.norm, self.gn_groups, self.activation = use_resize_conv, norm, gn_groups, activation
+        self.residual_layers = self.make_layers()
+        self.final_layer = DecoderBlock(self.residual_layers[-1].input_channels, output_channels,
+                                        time_embedding=time_embedding, activation=nn.Identity, compute_attn=False,
+                                        n_heads=n_heads, device=self.device, use_resize_conv=use_resize_conv, norm=norm,
+                                        gn_groups=gn_groups)
+        self.final_layer.norm1 = nn.Identity()            # reference :726-730
+        self.final_layer.norm2 = nn.Identity()
+        self.final_layer.activation = nn.Identity()
+
+    def make_layers(self, n: int = 4):
+        layers = []
+        for i in range(n):
+            in_ch = self.last_fmap_channels if i == 0 else layers[i - 1].output_channels
+            out_ch = in_ch // 2 if i != (n - 1) else self.first_fmap_channels
+            layers.append(DecoderBlock(in_ch, out_ch, time_embedding=self.time_embedding, compute_attn=(i < 2),
+                                       n_heads=self.n_heads, device=self.device, use_resize_conv=self.use_resize_conv,
+                                       norm=self.norm, gn_groups=self.gn_groups, activation=self.activation))
+        return nn.ModuleList(layers)
+
+
+_ACT_CODE = {nn.ReLU: N.RELU, nn.SiLU: N.SILU, nn.GELU: N.GELU, nn.Identity: N.NONE}
+
+
+class _Engine:
+    """One native model handle for a given split of the conditioning channels."""
+
+    def __init__(self, net: "ScoreNet", n_lsm: int, n_topo: int, n_cond: int):
+        enc, dec = net.encoder, net.decoder
+        if not dec.use_resize_conv:
+            raise NotImplementedError("model.use_resize_conv=false (ConvTranspose2d decoder) is not implemented natively")
+        if 1 + n_lsm + n_topo + n_cond != enc.input_channels:
+            raise ValueError(f"input channel mismatch: x(1)+lsm({n_lsm})+topo({n_topo})+cond_img({n_cond}) != "
+                             f"encoder.conv1 in_channels ({enc.input_channels})")
+        act = _ACT_CODE.get(dec.activation)
+        if act is None:
+            raise NotImplementedError(f"decoder activation {dec.activation} not implemented natively")
+        cfg = N.ModelConfig(n_lsm, n_topo, n_cond, enc.time_embedding, (C.c_int * 4)(*enc.block_layers), enc.n_heads,
+                            enc.num_classes or 0, dec.last_fmap_channels,
+                            N.NORM_GROUP if dec.norm == "group" else N.NORM_INSTANCE, dec.gn_groups, act,
+                            float(getattr(net, "sigma", 25.0)))
+        self.lib = N.lib()
+        h = C.c_void_p()
+        N.check(self.lib.sbgm_model_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+        self.version = None
+        self.names = [self.lib.sbgm_model_param_name(self.h, i).decode()
+                      for i in range(self.lib.sbgm_model_num_params(self.h))]
+
+    def __del__(self):
+        try:
+            if getattr(self, "h", None):
+                self.lib.sbgm_model_destroy(self.h)
+        except Exception:
+            pass
+
+    def upload(self, net: "ScoreNet"):
+        sd = net.state_dict(keep_vars=True)
+        ver = tuple((k, v.data_ptr(), v._version) for k, v in sd.items())
+        if ver == self.version:
+            return
+        missing = [k for k in self.names if k not in sd]
+        extra = [k for k in sd if k not in self.names]
+        if missing or extra:
+            raise N.NativeError(f"state_dict / engine key mismatch: missing {missing[:4]}, unexpected {extra[:4]}")
+        st = N.stream()
+        keep = []
+        for k, v in sd.items():
+            if k.endswith("num_batches_tracked"):
+                continue
+            N.require_device(v)
+            t = N.f32c(v.detach())
+            keep.append(t)
+            N.check(self.lib.sbgm_model_set_param(self.h, k.encode(), t.data_ptr(), t.numel(), st))
+        torch.cuda.current_stream().synchronize()       # `keep` may hold temporaries
+        N.check(self.lib.sbgm_model_check_complete(self.h))
+        self.version = ver
+
+    def download_bn_stats(self, net: "ScoreNet"):
+        """train-mode forwards update the engine's running statistics; mirror them into the module buffers"""
+        st = N.stream()
+        with torch.no_grad():
+            for k, v in net.state_dict(keep_vars=True).items():
+                if k.endswith("running_mean") or k.endswith("running_var"):
+                    N.check(self.lib.sbgm_model_get_param(self.h, k.encode(), v.data_ptr(), v.numel(), st))
+                elif k.endswith("num_batches_tracked"):
+                    v += 1
+        sd = net.state_dict(keep_vars=True)
+        self.version = tuple((k, v.data_ptr(), v._version) for k, v in sd.items())
+
+
+class ScoreNet(nn.Module):
+    """encoder -> decoder -> divide by sigma(t), evaluated by the native engine (reference score_unet.py:792-879)."""
+
+    def __init__(self, marginal_prob_std, encoder: nn.Module, decoder: nn.Module, device=None,
+                 debug_pre_sigma_div: bool = True):
+        super().__init__()
+        self.device = device or torch.device("cuda" if torch.cuda.is_available() else "cpu")
+        self.marginal_prob_std = marginal_prob_std
+        self.encoder, self.decoder = encoder, decoder
+        self.debug_pre_sigma_div = debug_pre_sigma_div
+        self.sigma = _sigma_of(marginal_prob_std)
+        self._engines = {}
+        self.to(self.device)
+
+    # -- engine plumbing -----------------------------------------------------------------------------------
+    def _engine(self, lsm_cond, topo_cond, cond_img) -> _Engine:
+        key = tuple(0 if c is None else int(c.shape[1]) for c in (lsm_cond, topo_cond, cond_img))
+        eng = self._engines.get(key)
+        if eng is None:
+            eng = self._engines[key] = _Engine(self, *key)
+        eng.upload(self)
+        return eng
+
+    def _prep(self, x, t, y, cond_img, lsm_cond, topo_cond):
+        N.require_device(x)
+        dev = x.device
+        for name, c in (("lsm_cond", lsm_cond), ("topo_cond", topo_cond)):
+            if c is not None and c.shape[0] != x.shape[0]:
+                raise ValueError(f"Batch mismatch: x= {x.shape[0]}, {name}={c.shape[0]}.")      # reference :275,:280
+        x = N.f32c(x.to(dev))
+        t = N.f32c(t.to(dev).view(-1))
+        if t.numel() != x.shape[0]:
+            raise ValueError(f"Batch mismatch: x= {x.shape[0]}, t={t.numel()}.")
+        y = None if y is None else y.to(dev).long().contiguous()
+        conds = [None if c is None else N.f32c(c.to(dev)) for c in (cond_img, lsm_cond, topo_cond)]
+        if x.dim() != 4 or x.shape[1] != 1:
+            raise ValueError(f"x must be [B,1,H,W], got {tuple(x.shape)}")
+        return (x, t, y, *conds)
+
+    def forward(self, x: torch.Tensor, t: torch.Tensor, y: Optional[torch.Tensor] = None,
+                cond_img: Optional[torch.Tensor] = None, lsm_cond: Optional[torch.Tensor] = None,
+                topo_cond: Optional[torch.Tensor] = None, *, _fmaps: Optional[list] = None):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError(
+                "backward through the native engine is not implemented yet (round 1 ships inference + sampling); "
+                "wrap evaluation in torch.no_grad() / inference_mode()")
+        x, t, y, cond_img, lsm_cond, topo_cond = self._prep(x, t, y, cond_img, lsm_cond, topo_cond)
+        eng = self._engine(lsm_cond, topo_cond, cond_img)
+        B, _, H, W = x.shape
+        out = torch.empty_like(x)
+        fm_ptrs = None
+        if _fmaps is not None:
+            hs = [(H // 2, W // 2), (H // 4, W // 4), (H // 8, W // 8), (H // 16, W // 16), (H // 32, W // 32)]
+            _fmaps[:] = [torch.empty(B, h, w, c, device=x.device) for (h, w), c in zip(hs, FMAP_CHANNELS)]
+            fm_ptrs = (C.c_void_p * 5)(*[f.data_ptr() for f in _fmaps])
+        train = self.training
+        N.check(eng.lib.sbgm_model_forward(eng.h, x.data_ptr(), t.data_ptr(), N.ptr(y), N.ptr(cond_img), N.ptr(lsm_cond),
+                                           N.ptr(topo_cond), out.data_ptr(), fm_ptrs, B, H, W, int(train), N.stream()))
+        if train:
+            eng.download_bn_stats(self)
+        if getattr(self, "debug_pre_sigma_div", False):
+            with torch.no_grad():      # reference :866-872 (logging only): undo the division for the statistic
+                pre = out * self.marginal_prob_std(t).view(-1, 1, 1, 1)
+                s = self.marginal_prob_std(t)
+                logger.info(f"[pre-σ-div] mean = {float(pre.mean()):.4g}, std = {float(pre.std()):.4g}, "
+                            f"σ ∈ [{s.min():.4g}, {s.max():.4g}]")
+        return out
+
+    def autotune(self, batch: int, height: int, width: int, cond_channels=(0, 0, 1)):
+        """time the conv tile candidates for this problem size once (optional)"""
+        shapes = [None if c == 0 else torch.empty(1, c, 1, 1) for c in cond_channels]
+        eng = self._engine(*shapes)
+        N.check(eng.lib.sbgm_model_autotune(eng.h, batch, height, width, N.stream()))
+
+
+def _sigma_of(fn) -> float:
+    kw = getattr(fn, "keywords", None) or {}
+    return float(kw.get("sigma", 25.0))
+
+
+# --------------------------------------------------------------------------------------------------------------
+# VE-SDE schedule (reference score_unet.py:881-934): [B]-sized host-orchestrated math, plain tensor ops
+# --------------------------------------------------------------------------------------------------------------
+def marginal_prob_std(t: torch.Tensor, sigma: float, eps: float = 1e-5) -> torch.Tensor:
+    t = t.to(dtype=torch.float32)
+    s = torch.tensor(sigma, dtype=t.dtype, device=t.device)
+    return torch.clamp(torch.sqrt((torch.exp((2.0 * t) * torch.log(s)) - 1.0) / (2.0 * torch.log(s))), min=eps)
+
+
+def diffusion_coeff(t, sigma, device=None):
+    return (sigma ** t).to(t.device)
+
+
+sigma = 25.0
+marginal_prob_std_fn = functools.partial(marginal_prob_std, sigma=sigma)
+diffusion_coeff_fn = functools.partial(diffusion_coeff, sigma=sigma)
+
+
+def loss_fn(model, x, marginal_prob_std, t_eps=1e-3, device=None, y=None, cond_img=None, lsm_cond=None,
+            topo_cond=None, sdf_cond=None):
+    """Denoising score-matching loss (reference score_unet.py:936-985): same RNG order (`rand(B)` then
+    `randn_like(x)`), same batch-size checks.  Usable under no_grad (validation); the training backward is not
+    implemented natively yet, so calling it with grad enabled raises from ScoreNet.forward."""
+    random_t = torch.rand(x.shape[0], device=x.device) * (1.0 - t_eps) + t_eps
+    z = torch.randn_like(x)
+    std = marginal_prob_std(random_t)
+    perturbed_x = x + std[:, None, None, None] * z
+    for name, arr in (("cond_img", cond_img), ("lsm_cond", lsm_cond), ("topo_cond", topo_cond), ("y", y)):
+        if arr is not None and arr.shape[0] != x.shape[0]:
+            raise ValueError(f"Batch size mismatch: x={x.shape[0]}, {name}={arr.shape[0]}")
+    score = model(perturbed_x, random_t, y=y, cond_img=cond_img, lsm_cond=lsm_cond, topo_cond=topo_cond)
+    if sdf_cond is not None:
+        w = (torch.sigmoid(sdf_cond) * 0.5 + 0.5).to(x.device)
+    else:
+        w = torch.ones_like(x)
+    return torch.mean(torch.sum(w * (score * std[:, None, None, None] + z) ** 2, dim=(1, 2, 3)))

@@ -1,0 +1,310 @@
+"""Per-kernel parity, through the C ABI, against plain PyTorch-CPU fp32 references of the same op.
+Tolerance: 1e-4 max-rel (north_star), most ops land at ~1e-6."""
+import ctypes as C
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from sbgm_danra_amd import _native as N  # noqa: E402
+
+DEV = "cuda"
+
+
+def lib():
+    return N.lib()
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def relerr(got, want):
+    return float((got - want).abs().max() / want.abs().max().clamp_min(1e-30))
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return torch.randn(*shape, generator=g) * scale
+
+
+def pad_c(c):
+    return 4 if c <= 4 else 8 if c <= 8 else (c + 15) // 16 * 16
+
+
+def run_conv(x, w, stride, pad, scale=None, bias=None, tbias=None, res=None, relu=False, after=False, tile=(0, 0), splits=0):
+    B, Cin, H, W = x.shape
+    Cout, _, KH, KW = w.shape
+    cp = pad_c(Cin)
+    xp = torch.zeros(B, H, W, cp)
+    xp[..., :Cin] = nhwc(x)
+    xd, wd = xp.to(DEV), w.contiguous().to(DEV)
+    packed = torch.empty(lib().sbgm_conv_packed_numel(Cout, KH, KW, cp), device=DEV)
+    N.check(lib().sbgm_conv_pack_weight(wd.data_ptr(), packed.data_ptr(), Cout, Cin, KH, KW, cp, N.stream()))
+    OH, OW = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    out = torch.empty(B, OH, OW, Cout, device=DEV)
+    dv = lambda t: None if t is None else t.contiguous().to(DEV)  # noqa: E731
+    sc, bi, tb, rs = dv(scale), dv(bias), dv(tbias), dv(None if res is None else nhwc(res))
+    ws = torch.empty(max(1, splits) * out.numel(), device=DEV)
+    a = N.ConvArgs(xd.data_ptr(), packed.data_ptr(), out.data_ptr(), N.ptr(sc), N.ptr(bi), N.ptr(tb), N.ptr(rs), B, H, W, cp,
+                   Cout, KH, KW, stride, pad, int(relu), int(after), tile[0], tile[1], splits, ws.data_ptr(), ws.numel())
+    N.check(lib().sbgm_conv2d_fwd(C.byref(a), N.stream()))
+    torch.cuda.synchronize()
+    return nchw(out.cpu())
+
+
+def ref_conv(x, w, stride, pad, scale=None, bias=None, tbias=None, res=None, relu=False, after=False):
+    y = F.conv2d(x, w, None, stride, pad)
+    if scale is not None:
+        y = y * scale.view(1, -1, 1, 1)
+    if bias is not None:
+        y = y + bias.view(1, -1, 1, 1)
+    if tbias is not None and not after:
+        y = y + tbias[:, :, None, None]
+    if res is not None:
+        y = y + res
+    if relu:
+        y = F.relu(y)
+    if tbias is not None and after:
+        y = y + tbias[:, :, None, None]
+    return y
+
+
+CONV_CASES = [
+    # (B, Cin, H, W, Cout, K, stride, pad)
+    (2, 2, 32, 32, 64, 8, 2, 3),     # stem conv1, 4-channel padded mode
+    (1, 7, 32, 32, 64, 8, 2, 3),     # stem conv1, 8-channel padded mode
+    (1, 13, 32, 32, 64, 8, 2, 3),    # stem conv1, 16-channel padded mode
+    (2, 64, 16, 16, 64, 8, 2, 3),    # stem conv2
+    (2, 64, 8, 8, 64, 3, 1, 1),      # layer1
+    (2, 64, 8, 8, 128, 3, 2, 1),     # layer2.0.conv1
+    (2, 64, 8, 8, 128, 1, 2, 0),     # downsample
+    (3, 128, 4, 4, 128, 3, 1, 1),
+    (1, 256, 2, 2, 512, 3, 2, 1),    # 2x2 -> 1x1 (64^2 input deepest stage), M < 16
+    (2, 64, 16, 20, 64, 3, 1, 1),    # non-square
+    (1, 256, 1, 24, 768, 1, 1, 0),   # linear: 24 tokens, C=256 -> 3C
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("tile", [(4, 4), (4, 2), (4, 1), (2, 4), (2, 2), (2, 1)])
+def test_conv_tiles(case, tile):
+    B, Cin, H, W, Cout, K, s, p = case
+    x, w = rnd(B, Cin, H, W), rnd(Cout, Cin, K, K, seed=1, scale=1.0 / math.sqrt(Cin * K * K))
+    got = run_conv(x, w, s, p, tile=tile)
+    assert relerr(got, ref_conv(x, w, s, p)) < 2e-5
+
+
+@pytest.mark.parametrize("splits", [2, 3, 4, 9])
+def test_conv_splitk_epilogue(splits):
+    B, Cin, H, W, Cout = 2, 128, 4, 4, 128
+    x, w = rnd(B, Cin, H, W), rnd(Cout, Cin, 3, 3, seed=2, scale=0.03)
+    kw = dict(scale=rnd(Cout, seed=3).abs() + 0.5, bias=rnd(Cout, seed=4), tbias=rnd(B, Cout, seed=5), res=rnd(B, Cout, H, W, seed=6),
+              relu=True, after=True)
+    got = run_conv(x, w, 1, 1, tile=(4, 2), splits=splits, **kw)
+    assert relerr(got, ref_conv(x, w, 1, 1, **kw)) < 2e-5
+
+
+@pytest.mark.parametrize("after", [False, True])
+def test_conv_epilogue(after):
+    B, Cin, H, W, Cout = 2, 64, 8, 8, 64
+    x, w = rnd(B, Cin, H, W), rnd(Cout, Cin, 3, 3, seed=2, scale=0.04)
+    kw = dict(scale=rnd(Cout, seed=3).abs() + 0.5, bias=rnd(Cout, seed=4), tbias=rnd(B, Cout, seed=5), res=rnd(B, Cout, H, W, seed=6),
+              relu=True, after=after)
+    got = run_conv(x, w, 1, 1, **kw)
+    assert relerr(got, ref_conv(x, w, 1, 1, **kw)) < 2e-5
+
+
+def test_pack_input_and_transposes():
+    B, H, W = 2, 8, 12
+    srcs = [rnd(B, 1, H, W), rnd(B, 2, H, W, seed=1), rnd(B, 2, H, W, seed=2), rnd(B, 3, H, W, seed=3)]
+    dv = [s.to(DEV) for s in srcs]
+    out = torch.empty(B, H, W, 8, device=DEV)
+    ptrs = (C.c_void_p * 4)(*[d.data_ptr() for d in dv])
+    chs = (C.c_int * 4)(1, 2, 2, 3)
+    N.check(lib().sbgm_pack_input(ptrs, chs, 4, out.data_ptr(), B, H, W, 8, N.stream()))
+    want = nhwc(torch.cat(srcs, 1))
+    assert torch.equal(out.cpu(), want)
+    x = rnd(B, 40, H, W).to(DEV)
+    y = torch.empty(B, H, W, 40, device=DEV)
+    N.check(lib().sbgm_nchw_to_nhwc(x.data_ptr(), y.data_ptr(), B, H, W, 40, N.stream()))
+    assert torch.equal(y.cpu(), nhwc(x.cpu()))
+    z = torch.empty_like(x)
+    N.check(lib().sbgm_nhwc_to_nchw(y.data_ptr(), z.data_ptr(), B, H, W, 40, N.stream()))
+    assert torch.equal(z.cpu(), x.cpu())
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 4, 4), (1, 128, 8, 6), (2, 512, 1, 1)])
+def test_upsample2x(shape):
+    x = rnd(*shape)
+    B, Cc, H, W = shape
+    xd = nhwc(x).to(DEV)
+    y = torch.empty(B, 2 * H, 2 * W, Cc, device=DEV)
+    N.check(lib().sbgm_upsample2x_fwd(xd.data_ptr(), y.data_ptr(), B, H, W, Cc, N.stream()))
+    want = F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False)
+    assert relerr(nchw(y.cpu()), want) < 1e-6
+
+
+@pytest.mark.parametrize("C_,G,hw", [(64, 8, 64 * 64), (512, 8, 16), (128, 128, 100), (256, 8, 4)])
+@pytest.mark.parametrize("full", [False, True])
+def test_groupnorm(C_, G, hw, full):
+    B = 3
+    H = int(math.isqrt(hw)) if math.isqrt(hw) ** 2 == hw else 1
+    W = hw // H
+    x = rnd(B, C_, H, W) * 3 + 0.7
+    affine = G != C_
+    gamma, beta = (rnd(C_, seed=1), rnd(C_, seed=2)) if affine else (None, None)
+    skip, tb = (rnd(B, C_, H, W, seed=3), rnd(B, C_, seed=4)) if full else (None, None)
+    xd = nhwc(x).to(DEV)
+    y = torch.empty_like(xd)
+    ws = torch.empty(24 * B * G + 64, dtype=torch.uint8, device=DEV)
+    dv = lambda t: None if t is None else t.contiguous().to(DEV)  # noqa: E731
+    g_, b_, s_, t_ = dv(gamma), dv(beta), dv(None if skip is None else nhwc(skip)), dv(tb)
+    N.check(lib().sbgm_groupnorm_fwd(xd.data_ptr(), y.data_ptr(), N.ptr(g_), N.ptr(b_), N.ptr(s_), N.ptr(t_),
+                                     N.SILU if full else N.NONE, B, H * W, C_, G, 1e-5, ws.data_ptr(), N.stream()))
+    want = F.group_norm(x, G, gamma, beta, 1e-5)
+    if full:
+        want = F.silu(want + skip + tb[:, :, None, None])
+    assert relerr(nchw(y.cpu()), want) < 1e-5
+
+
+@pytest.mark.parametrize("M,C_", [(64, 256), (7, 512), (300, 128), (5, 64)])
+def test_layernorm(M, C_):
+    x, g, b = rnd(M, C_) * 2 + 1, rnd(C_, seed=1), rnd(C_, seed=2)
+    xd, gd, bd = x.to(DEV), g.to(DEV), b.to(DEV)
+    y = torch.empty_like(xd)
+    N.check(lib().sbgm_layernorm_fwd(xd.data_ptr(), y.data_ptr(), gd.data_ptr(), bd.data_ptr(), M, C_, 1e-5, N.stream()))
+    assert relerr(y.cpu(), F.layer_norm(x, (C_,), g, b, 1e-5)) < 1e-5
+
+
+@pytest.mark.parametrize("with_res", [False, True])
+def test_batchnorm_train(with_res):
+    B, C_, H, W = 4, 128, 6, 6
+    x = rnd(B, C_, H, W) * 2 + 0.5
+    g, b = rnd(C_, seed=1), rnd(C_, seed=2)
+    rm, rv = rnd(C_, seed=3) * 0.1, rnd(C_, seed=4).abs() + 0.5
+    res, tb = (rnd(B, C_, H, W, seed=5), rnd(B, C_, seed=6)) if with_res else (None, None)
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    want = F.batch_norm(x, rm_ref, rv_ref, g, b, True, 0.1, 1e-5)
+    if with_res:
+        want = F.relu(want + res) + tb[:, :, None, None]
+    xd, gd, bd, rmd, rvd = nhwc(x).to(DEV), g.to(DEV), b.to(DEV), rm.to(DEV), rv.to(DEV)
+    rd = None if res is None else nhwc(res).to(DEV)
+    td = None if tb is None else tb.to(DEV)
+    y = torch.empty_like(xd)
+    ws = torch.empty(24 * C_ + 64, dtype=torch.uint8, device=DEV)
+    N.check(lib().sbgm_batchnorm_train_fwd(xd.data_ptr(), y.data_ptr(), gd.data_ptr(), bd.data_ptr(), rmd.data_ptr(), rvd.data_ptr(),
+                                           N.ptr(rd), N.ptr(td), int(with_res), B, H * W, C_, 1e-5, 0.1, ws.data_ptr(), N.stream()))
+    assert relerr(nchw(y.cpu()), want) < 1e-5
+    assert relerr(rmd.cpu(), rm_ref) < 1e-5 and relerr(rvd.cpu(), rv_ref) < 1e-5
+
+
+@pytest.mark.parametrize("B,S,C_,heads", [(2, 64, 256, 4), (2, 16, 512, 4), (1, 256, 128, 4), (3, 4, 256, 2), (1, 1024, 128, 8),
+                                          (2, 40, 128, 1)])
+def test_mha_core(B, S, C_, heads):
+    qkv = rnd(B, S, 3 * C_)
+    d = C_ // heads
+    q, k, v = [t.view(B, S, heads, d).transpose(1, 2) for t in qkv.split(C_, dim=-1)]
+    att = torch.softmax((q / math.sqrt(d)) @ k.transpose(-1, -2), -1) @ v
+    want = att.transpose(1, 2).reshape(B, S, C_)
+    qd = qkv.to(DEV)
+    out = torch.empty(B, S, C_, device=DEV)
+    N.check(lib().sbgm_mha_core_fwd(qd.data_ptr(), out.data_ptr(), B, S, C_, heads, N.stream()))
+    assert relerr(out.cpu(), want) < 1e-5
+
+
+def test_mha_online_softmax_rescale_branch():
+    """spike late keys so the running max jumps in a later key block (guide rule: force the rescale path)"""
+    B, S, C_, heads = 1, 64, 64, 2
+    qkv = rnd(B, S, 3 * C_)
+    qkv[0, 50, C_:2 * C_] *= 25.0          # key 50 dominates every query that aligns with it
+    d = C_ // heads
+    q, k, v = [t.view(B, S, heads, d).transpose(1, 2) for t in qkv.split(C_, dim=-1)]
+    want = (torch.softmax((q.double() / math.sqrt(d)) @ k.double().transpose(-1, -2), -1) @ v.double()).float()
+    want = want.transpose(1, 2).reshape(B, S, C_)
+    qd = qkv.to(DEV)
+    out = torch.empty(B, S, C_, device=DEV)
+    N.check(lib().sbgm_mha_core_fwd(qd.data_ptr(), out.data_ptr(), B, S, C_, heads, N.stream()))
+    assert relerr(out.cpu(), want) < 1e-5
+
+
+@pytest.mark.parametrize("with_y", [False, True])
+def test_time_projection(with_y):
+    B, D, ch = 5, 256, 128
+    t = torch.tensor([1e-3, 0.013, 0.37, 0.81, 1.0])
+    freqs = rnd(D // 2) * 30.0
+    w, b = rnd(ch, D, seed=1) * 0.05, rnd(ch, seed=2)
+    table = rnd(5, D, seed=3)
+    table[0] = 0
+    y = torch.tensor([0, 3, 1, 4, 2]) if with_y else None
+    p = t[:, None] * freqs[None, :] * (2.0 * torch.pi)
+    emb = torch.cat([p.sin(), p.cos()], -1)
+    if with_y:
+        emb = emb + table[y]
+    want = F.linear(F.silu(emb), w, b)
+    td, fd, wd, bd, tabd = t.to(DEV), freqs.to(DEV), w.to(DEV), b.to(DEV), table.to(DEV)
+    yd = None if y is None else y.to(DEV)
+    out, ws = torch.empty(B, ch, device=DEV), torch.empty(B * D, device=DEV)
+    N.check(lib().sbgm_time_proj_fwd(td.data_ptr(), N.ptr(yd), tabd.data_ptr() if with_y else None, fd.data_ptr(), wd.data_ptr(),
+                                     bd.data_ptr(), out.data_ptr(), ws.data_ptr(), B, D, ch, N.stream()))
+    assert relerr(out.cpu(), want) < 2e-5
+
+
+def test_conv3x3_cout1_with_sigma_division():
+    B, C_, H, W = 2, 64, 12, 10
+    x, w, b = rnd(B, C_, H, W), rnd(1, C_, 3, 3, seed=1) * 0.05, rnd(1, seed=2)
+    t = torch.tensor([0.002, 0.9])
+    ls = math.log(25.0)
+    std = torch.sqrt((torch.exp(2 * t * ls) - 1) / (2 * ls)).clamp_min(1e-5)
+    want = F.conv2d(x, w, b, 1, 1) / std.view(-1, 1, 1, 1)
+    xd, wd, bd, td = nhwc(x).to(DEV), w.to(DEV), b.to(DEV), t.to(DEV)
+    wp = torch.empty(9 * C_, device=DEV)
+    N.check(lib().sbgm_cout1_pack_weight(wd.data_ptr(), wp.data_ptr(), C_, N.stream()))
+    out = torch.empty(B, 1, H, W, device=DEV)
+    N.check(lib().sbgm_conv3x3_cout1_fwd(xd.data_ptr(), wp.data_ptr(), bd.data_ptr(), td.data_ptr(), 25.0, out.data_ptr(), B, H, W, C_,
+                                         N.stream()))
+    assert relerr(out.cpu(), want) < 1e-5
+
+
+def test_sampler_update_kernels():
+    B, H = 3, 16
+    x, s, z = rnd(B, 1, H, H) * 10, rnd(B, 1, H, H, seed=1), rnd(B, 1, H, H, seed=2)
+    g2, dt, nc = 3.7, 0.001, 0.06
+    xd, sd, zd = x.to(DEV), s.to(DEV), z.to(DEV)
+    xm = torch.empty_like(xd)
+    N.check(lib().sbgm_em_step(xd.data_ptr(), xm.data_ptr(), sd.data_ptr(), zd.data_ptr(), g2, dt, nc, 0, 0, x.numel(), N.stream()))
+    mean = x + (g2 * s) * dt
+    assert relerr(xm.cpu(), mean) < 1e-6 and relerr(xd.cpu(), mean + nc * z) < 1e-6
+    # Langevin
+    xd = x.to(DEV)
+    snr_nn = 0.16 * math.sqrt(H * H)
+    ws = torch.empty(B, dtype=torch.float64, device=DEV)
+    N.check(lib().sbgm_langevin_step(xd.data_ptr(), sd.data_ptr(), zd.data_ptr(), snr_nn, ws.data_ptr(), 0, 0, B, H * H, N.stream()))
+    gn = torch.norm(s.reshape(B, -1), dim=-1).mean()
+    eps = 2 * (snr_nn / gn) ** 2
+    assert relerr(xd.cpu(), x + eps * s + torch.sqrt(2 * eps) * z) < 1e-5
+    # CFG combine
+    od = torch.empty_like(sd)
+    N.check(lib().sbgm_cfg_combine(od.data_ptr(), sd.data_ptr(), zd.data_ptr(), 1.5, s.numel(), N.stream()))
+    assert relerr(od.cpu(), 2.5 * s - 1.5 * z) < 1e-6
+
+
+def test_philox_normal_statistics_and_streams():
+    n = 1 << 20
+    a, b = torch.empty(n, device=DEV), torch.empty(n, device=DEV)
+    N.check(lib().sbgm_randn_scaled(a.data_ptr(), 2.0, 1234, 0, n, N.stream()))
+    N.check(lib().sbgm_randn_scaled(b.data_ptr(), 2.0, 1234, 1, n, N.stream()))
+    a, b = a.cpu().double(), b.cpu().double()
+    assert abs(a.mean()) < 0.01 and abs(a.std() - 2.0) < 0.01
+    assert abs(((a / 2) ** 4).mean() - 3.0) < 0.05                       # kurtosis of a normal
+    assert abs((a * b).mean()) < 0.02 and not torch.equal(a, b)           # independent draws per index
+    c = torch.empty(n, device=DEV)
+    N.check(lib().sbgm_randn_scaled(c.data_ptr(), 2.0, 1234, 0, n, N.stream()))
+    assert torch.equal(c.cpu().double(), a)                               # counter-based: reproducible
