@@ -75,13 +75,17 @@ struct sbgm_model {
     int table_cap = 0;
     std::map<ConvOpKey, ConvTile> tuned;
     bool tuning = false;
-    hipStream_t tune_stream = nullptr;
+    hipStream_t graph_stream = nullptr;     // private capture stream (the caller's may be the legacy default stream)
+    hipEvent_t ev_in = nullptr, ev_out = nullptr;
 
     ~sbgm_model() {
         if (arena) (void)hipFree(arena);
         if (ws) (void)hipFree(ws);
         if (d_state) (void)hipFree(d_state);
         if (d_table) (void)hipFree(d_table);
+        if (graph_stream) (void)hipStreamDestroy(graph_stream);
+        if (ev_in) (void)hipEventDestroy(ev_in);
+        if (ev_out) (void)hipEventDestroy(ev_out);
     }
 
     Param* add(const std::string& name, ParamKind kind, int64_t numel) {
@@ -121,11 +125,18 @@ struct sbgm_model {
 
     int build(const sbgm_model_config& c);
     int ensure_ws(size_t bytes);
-    float* wsalloc(size_t floats) {
+    float* wsalloc(size_t floats) {     // bump allocator over the activation workspace; nullptr (+ error text) when full
+        const size_t bytes = align_up(floats * 4, 256);
+        if (ws_used + bytes > ws_bytes) {
+            sbgm_set_error("workspace exhausted: need %zu more bytes at offset %zu of %zu", bytes, ws_used, ws_bytes);
+            return nullptr;
+        }
         float* p = reinterpret_cast<float*>(ws + ws_used);
-        ws_used += align_up(floats * 4, 256);
+        ws_used += bytes;
         return p;
     }
+    float* partial = nullptr;           // split-K scratch shared by every convolution of a forward (stream-ordered reuse)
+    static constexpr size_t PARTIAL_FLOATS = 16u << 20;   // 64 MiB
     size_t fwd_need(int B, int H, int W) const;
     size_t sampler_keep(int B, int H, int W) const {
         const size_t n = (size_t)B * H * W;
@@ -276,7 +287,7 @@ size_t sbgm_model::fwd_need(int B, int H, int W) const {
     const size_t px = (size_t)B * H * W;
     // NHWC floats per input pixel summed over all intermediates (encoder ~ 64/4*3 + ..., decoder dominated by the
     // final block's 3 x 64 channels at full resolution); 1024 floats/pixel is > 2x the true footprint.
-    return px * 1024 * 4 + (64u << 20);
+    return px * 1024 * 4 + PARTIAL_FLOATS * 4 + (64u << 20);
 }
 
 int sbgm_model::fold_bn(hipStream_t st) {
@@ -341,42 +352,41 @@ int sbgm_model::conv(const ConvGeom& g, ConvParams p, hipStream_t st) {
             SBGM_HIP(hipEventCreate(&e1));
             float best = 1e30f;
             ConvTile best_t = pick_tile(g, p);
-            float* part = nullptr;
             for (auto& ct : cands) {
-                const size_t need = ct.splits > 1 ? mc * ct.splits : 0;
-                const size_t save = ws_used;
-                if (ws_used + need * 4 + 256 > ws_bytes) continue;
-                part = need ? wsalloc(need) : nullptr;
+                if (ct.splits > 1 && mc * ct.splits > PARTIAL_FLOATS) continue;
                 for (int rep = 0; rep < 4; ++rep) {
                     if (rep == 1) SBGM_HIP(hipEventRecord(e0, st));
-                    if (sbgm_launch_conv(g, p, ct, part, st)) return 1;
+                    if (sbgm_launch_conv(g, p, ct, partial, st)) return 1;
                 }
                 SBGM_HIP(hipEventRecord(e1, st));
                 SBGM_HIP(hipEventSynchronize(e1));
                 float ms = 0.f;
                 SBGM_HIP(hipEventElapsedTime(&ms, e0, e1));
                 if (ms < best) { best = ms; best_t = ct; }
-                ws_used = save;
             }
             (void)hipEventDestroy(e0);
             (void)hipEventDestroy(e1);
             tuned[key] = best_t;
         }
     }
-    const ConvTile ct = pick_tile(g, p);
-    float* part = nullptr;
-    if (ct.splits > 1) part = wsalloc(mc * ct.splits);
-    return sbgm_launch_conv(g, p, ct, part, st);
+    ConvTile ct = pick_tile(g, p);
+    if (ct.splits > 1 && mc * ct.splits > PARTIAL_FLOATS) ct.splits = (int)std::max<size_t>(1, PARTIAL_FLOATS / mc);
+    return sbgm_launch_conv(g, p, ct, partial, st);
 }
 
 // y = h + FF(LN2(h)),  h = x + MHA(LN1(x))   over tokens [B*S, C]  (score_unet.py:136-148); in place on x
 int sbgm_model::attention(const AttnW& a, float* x, int B, int S, hipStream_t st) {
     const int C = a.C, M = B * S;
     float* n1 = wsalloc((size_t)M * C);
+    if (!n1) return 1;
     float* qkv = wsalloc((size_t)M * 3 * C);
+    if (!qkv) return 1;
     float* att = wsalloc((size_t)M * C);
+    if (!att) return 1;
     float* h = wsalloc((size_t)M * C);
+    if (!h) return 1;
     float* f1 = wsalloc((size_t)M * C);
+    if (!f1) return 1;
     const ConvGeom lin{1, 1, 1, 0};
     if (sbgm_launch_layernorm(x, n1, a.ln1g->dev, a.ln1b->dev, M, C, LN_EPS, st)) return 1;
     ConvParams p{};
@@ -410,12 +420,15 @@ int sbgm_model::forward(const float* x, const float* t, const int64_t* y, const 
         ws_used = 0;
     }
     if (bn_dirty && fold_bn(st)) return 1;
+    partial = wsalloc(PARTIAL_FLOATS);
+    if (!partial) return 1;
 
     // ---- pack inputs, time embedding -------------------------------------------------------------------------------
     PackSrc src{};
     auto push = [&](const float* p, int c) { if (p && c) { src.ptr[src.n] = p; src.ch[src.n] = c; ++src.n; } };
     push(x, 1); push(lsm, cfg.n_lsm_channels); push(topo, cfg.n_topo_channels); push(cond, cfg.n_cond_channels);
     float* x0 = wsalloc((size_t)B * H * W * cs_in);
+    if (!x0) return 1;
     if (sbgm_launch_pack_input(src, x0, B, H, W, cs_in, st)) return 1;
 
     TimeEmbedArgs te{};
@@ -425,14 +438,17 @@ int sbgm_model::forward(const float* x, const float* t, const int64_t* y, const 
     te.freqs[0] = enc_freq->dev;
     for (int i = 0; i < 4; ++i) te.freqs[1 + i] = dec[i].freq->dev;
     te.emb_ws = wsalloc((size_t)5 * B * D);
+    if (!te.emb_ws) return 1;
     float* tb[9];
     te.n_proj = 9;
     for (int i = 0; i < 5; ++i) {
         tb[i] = wsalloc((size_t)B * FMAP_CH[i]);
+        if (!tb[i]) return 1;
         te.proj[i] = TimeProj{enc_tpw[i]->dev, enc_tpb[i]->dev, tb[i], FMAP_CH[i], 0};
     }
     for (int i = 0; i < 4; ++i) {
         tb[5 + i] = wsalloc((size_t)B * dec[i].cout);
+        if (!tb[5 + i]) return 1;
         te.proj[5 + i] = TimeProj{dec[i].tpw->dev, dec[i].tpb->dev, tb[5 + i], dec[i].cout, 1 + i};
     }
     if (sbgm_launch_time_embed(te, st)) return 1;
@@ -440,6 +456,7 @@ int sbgm_model::forward(const float* x, const float* t, const int64_t* y, const 
     // 24 B per statistic: B*G for GroupNorm (G = C for InstanceNorm), C for BatchNorm
     const size_t n_stats = std::max<size_t>(512, (size_t)B * (cfg.decoder_norm == SBGM_NORM_GROUP ? std::min(cfg.gn_groups, 512) : 512));
     double* stats = reinterpret_cast<double*>(wsalloc(n_stats * 6));
+    if (!stats) return 1;
 
     // conv + BatchNorm (+res, relu, late time bias): eval folds BN into the conv epilogue, train runs it after
     auto conv_bn = [&](const ConvGeom& g, const float* in, int h, int w, int cs, const ConvW& cw, BNW& bnw, int cout,
@@ -453,6 +470,7 @@ int sbgm_model::forward(const float* x, const float* t, const int64_t* y, const 
         }
         const int oh = (h + 2 * g.pad - g.kh) / g.stride + 1, ow = (w + 2 * g.pad - g.kw) / g.stride + 1;
         float* raw = wsalloc((size_t)B * oh * ow * cout);
+        if (!raw) return 1;
         p.out = raw;
         if (conv(g, p, st)) return 1;
         return sbgm_launch_batchnorm_train(raw, o, bnw.g->dev, bnw.b->dev, bnw.rm->dev, bnw.rv->dev, res, tb_after, relu, B,
@@ -464,6 +482,7 @@ int sbgm_model::forward(const float* x, const float* t, const int64_t* y, const 
     int fh[5], fw[5];
     fh[0] = H / 2; fw[0] = W / 2;
     fm[0] = wsalloc((size_t)B * fh[0] * fw[0] * 64);
+    if (!fm[0]) return 1;
     {
         ConvParams p{};
         p.x = x0; p.wp = conv1.w->dev; p.out = fm[0]; p.tbias = tb[0]; p.B = B; p.H = H; p.W = W; p.Cs = cs_in; p.Cout = 64;
@@ -471,6 +490,7 @@ int sbgm_model::forward(const float* x, const float* t, const int64_t* y, const 
     }
     int ch = H / 4, cw_ = W / 4;
     float* cur = wsalloc((size_t)B * ch * cw_ * 64);
+    if (!cur) return 1;
     if (conv_bn(ConvGeom{8, 8, 2, 3}, fm[0], fh[0], fw[0], 64, conv2, bn1, 64, nullptr, true, nullptr, cur)) return 1;   // :321-325
     int cc = 64;
     for (int li = 0; li < 4; ++li) {
@@ -479,14 +499,17 @@ int sbgm_model::forward(const float* x, const float* t, const int64_t* y, const 
             BlockW& b = layers[li][bi];
             const int oh = ch / b.stride, ow = cw_ / b.stride;
             float* y1 = wsalloc((size_t)B * oh * ow * b.cout);
+            if (!y1) return 1;
             if (conv_bn(ConvGeom{3, 3, b.stride, 1}, cur, ch, cw_, cc, b.c1, b.bn1, b.cout, nullptr, true, nullptr, y1)) return 1;
             const float* idn = cur;
             if (b.has_ds) {
                 float* d = wsalloc((size_t)B * oh * ow * b.cout);
+                if (!d) return 1;
                 if (conv_bn(ConvGeom{1, 1, b.stride, 0}, cur, ch, cw_, cc, b.ds, b.dsbn, b.cout, nullptr, false, nullptr, d)) return 1;
                 idn = d;
             }
             float* y2 = wsalloc((size_t)B * oh * ow * b.cout);
+            if (!y2) return 1;
             const float* tba = (bi == nb - 1) ? tb[li + 1] : nullptr;                        // fmap + t_emb (:332,341,350,359)
             if (conv_bn(ConvGeom{3, 3, 1, 1}, y1, oh, ow, b.cout, b.c2, b.bn2, b.cout, idn, true, tba, y2)) return 1;
             cur = y2; ch = oh; cw_ = ow; cc = b.cout;
@@ -509,14 +532,17 @@ int sbgm_model::forward(const float* x, const float* t, const int64_t* y, const 
         const int oh = 2 * ch, ow = 2 * cw_;
         SBGM_CHECK(oh == fh[3 - i] && ow == fw[3 - i] && d.cout == FMAP_CH[3 - i], "decoder/skip shape mismatch at block %d", i);
         float* up = wsalloc((size_t)B * oh * ow * d.cin);
+        if (!up) return 1;
         if (sbgm_launch_upsample2x(cur, up, B, ch, cw_, d.cin, st)) return 1;
         float* a = wsalloc((size_t)B * oh * ow * d.cin);
+        if (!a) return 1;
         ConvParams p{};
         p.x = up; p.wp = d.up.w->dev; p.out = a; p.bias = d.up.b->dev; p.B = B; p.H = oh; p.W = ow; p.Cs = d.cin; p.Cout = d.cin;
         if (conv(ConvGeom{3, 3, 1, 1}, p, st)) return 1;
         if (sbgm_launch_groupnorm(a, a, d.n1g ? d.n1g->dev : nullptr, d.n1b ? d.n1b->dev : nullptr, nullptr, nullptr,
                                   SBGM_ACT_NONE, B, oh * ow, d.cin, groups(d.cin), GN_EPS, stats, st)) return 1;
         float* c2 = wsalloc((size_t)B * oh * ow * d.cout);
+        if (!c2) return 1;
         p.x = a; p.wp = d.conv.w->dev; p.out = c2; p.bias = d.conv.b->dev; p.Cout = d.cout;
         if (conv(ConvGeom{3, 3, 1, 1}, p, st)) return 1;
         if (sbgm_launch_groupnorm(c2, c2, d.n2g ? d.n2g->dev : nullptr, d.n2b ? d.n2b->dev : nullptr, fm[3 - i], tb[5 + i],
@@ -527,8 +553,10 @@ int sbgm_model::forward(const float* x, const float* t, const int64_t* y, const 
     {   // final block: no norms, no skip, no time, identity activation (score_unet.py:726-730, :757)
         const int ci = dec[3].cout;
         float* up = wsalloc((size_t)B * H * W * ci);
+        if (!up) return 1;
         if (sbgm_launch_upsample2x(cur, up, B, ch, cw_, ci, st)) return 1;
         float* a = wsalloc((size_t)B * H * W * ci);
+        if (!a) return 1;
         ConvParams p{};
         p.x = up; p.wp = fin_up.w->dev; p.out = a; p.bias = fin_up.b->dev; p.B = B; p.H = H; p.W = W; p.Cs = ci; p.Cout = ci;
         if (conv(ConvGeom{3, 3, 1, 1}, p, st)) return 1;
@@ -547,7 +575,21 @@ static std::vector<float> linspace_f32(float start, float end, int n) {
     return v;
 }
 
-int sbgm_model::sampler(const sbgm_sampler_args& a, hipStream_t st) {
+int sbgm_model::sampler(const sbgm_sampler_args& a, hipStream_t caller) {
+    // Graph capture is illegal on the legacy default stream, so the captured loop runs on a private stream that is
+    // fenced against the caller's stream with events on both sides.
+    hipStream_t st = caller;
+    const bool graphed = a.use_graph && !a.noise;
+    if (graphed) {
+        if (!graph_stream) {
+            SBGM_HIP(hipStreamCreateWithFlags(&graph_stream, hipStreamNonBlocking));
+            SBGM_HIP(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
+            SBGM_HIP(hipEventCreateWithFlags(&ev_out, hipEventDisableTiming));
+        }
+        SBGM_HIP(hipEventRecord(ev_in, caller));
+        SBGM_HIP(hipStreamWaitEvent(graph_stream, ev_in, 0));
+        st = graph_stream;
+    }
     SBGM_CHECK(a.kind == SBGM_SAMPLER_EM || a.kind == SBGM_SAMPLER_PC, "sampler: unknown kind %d", a.kind);
     SBGM_CHECK(a.num_steps >= 2, "sampler: num_steps=%d must be >= 2 (step size = t0 - t1)", a.num_steps);
     SBGM_CHECK(a.out != nullptr, "sampler: out is required");
@@ -620,7 +662,7 @@ int sbgm_model::sampler(const sbgm_sampler_args& a, hipStream_t st) {
     const size_t saved_ws = ws_bytes;
     ws_bytes = fwd_bytes;            // forward() must not touch the sampler slabs
     int rc = 0;
-    if (a.use_graph && !z) {
+    if (graphed) {
         hipGraph_t graph = nullptr;
         hipGraphExec_t exec = nullptr;
         hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
@@ -646,6 +688,10 @@ int sbgm_model::sampler(const sbgm_sampler_args& a, hipStream_t st) {
     ws_bytes = saved_ws;
     if (rc) return rc;
     SBGM_HIP(hipMemcpyAsync(a.out, xmean, n * 4, hipMemcpyDeviceToDevice, st));
+    if (graphed) {
+        SBGM_HIP(hipEventRecord(ev_out, st));
+        SBGM_HIP(hipStreamWaitEvent(caller, ev_out, 0));
+    }
     return 0;
 }
 
