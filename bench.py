@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""bench.py — reverse-SDE sampling throughput of the native score-UNet path on MI355X.
+
+Workload (BASELINE.json configs[1]): 128x128 target, 1 LR condition (C_in = 2), batch 32 per GPU, VE-SDE
+Euler-Maruyama sampling; one "step" = one SDE step = one network evaluation + the fused update over the batch.
+Metric: denoising steps / s = batch x SDE steps / wall-second, whole job (sum over ranks; each rank owns whole
+independent batches, no data-path collective => "weak" scaling).
+
+    python bench.py --gpus 1 --steps 200 --warmup 20
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     : the implicit-GEMM convolution kernel family (dominant: ~95 % of evaluation time), algorithmic
+                 FLOPs (2*M*Cout*K) / summed launch durations measured with HIP events on the launch
+                 stream, against the fp32 matrix/vector peak (157.3 TFLOP/s, MI355X_MICROARCH.md).
+  cpu_baseline : the CPU oracle (oracle/torch_ref.py, kind "port") timed on this box's host cores on a bounded
+                 sample of the same workload.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_TFLOPS = 157.3          # MI355X fp32 vector == fp32 MFMA peak (guide: chip-level parameters)
+PEAK_HBM_GBS = 8000.0
+FLOP_PER_SAMPLE_128 = 5.146e9     # SURVEY.md §8d, 128x128, C_in = 2
+BYTES_PER_EVAL = lambda b, hw: 76.2e6 + 29.2e6 * b * (hw / 128.0) ** 2   # noqa: E731  layer-fused model, SURVEY §8d
+
+
+def build_model(dev, n_cond=1):
+    import sbgm_danra_amd as S
+    torch.manual_seed(42)
+    enc = S.Encoder(n_cond, 256, block_layers=[2, 2, 2, 2], n_heads=4)
+    dec = S.Decoder(512, 1, 256, n_heads=4, norm="group", gn_groups=8, activation=nn.SiLU)
+    net = S.ScoreNet(S.marginal_prob_std_fn, enc, dec, device=dev, debug_pre_sigma_div=False)
+    with torch.no_grad():                                  # reference training init (training.py:188-201)
+        for m in net.modules():
+            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                nn.init.xavier_uniform_(m.weight)
+                if m.bias is not None:
+                    m.bias.fill_(0.01)
+    net.eval()
+    return net
+
+
+def cpu_baseline(batch, hw, budget_s=20.0):
+    """Oracle on the host cores: 1 warm-up + as many Euler-Maruyama steps as fit the budget (at least 2)."""
+    from oracle import torch_ref as O
+    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    cores = min(cores, 16)             # the GPU box gives one GPU job a 16-core CPU share; more threads only thrash
+    torch.set_num_threads(cores)
+    torch.manual_seed(42)
+    ora = O.build_scorenet(1).eval()
+    x, c = torch.randn(batch, 1, hw, hw), torch.randn(batch, 1, hw, hw)
+    t = torch.full((batch,), 0.5)
+    with torch.no_grad():
+        ora(x, t, cond_img=c)
+        n, t0 = 0, time.perf_counter()
+        while n < 2 or (time.perf_counter() - t0) < budget_s * 0.6:
+            s = ora(x, t, cond_img=c)
+            x = x + 1e-3 * s + 0.03 * torch.randn_like(x)
+            n += 1
+            if n >= 50:
+                break
+        dt = time.perf_counter() - t0
+    model = ""
+    try:
+        with open("/proc/cpuinfo") as f:
+            model = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
+    except Exception:
+        pass
+    return {"value": batch * n / dt, "unit": "denoising steps/s", "cores": cores, "kind": "port",
+            "sample": f"{n} Euler-Maruyama steps of the CPU oracle at batch {batch}, {hw}x{hw}, after 1 warm-up "
+                      f"({dt:.1f} s, PyTorch-CPU {torch.__version__}, {model})"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--batch", type=int, default=32)
+    ap.add_argument("--size", type=int, default=128)
+    ap.add_argument("--sampler", choices=["em", "pc"], default="em")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-autotune", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-csv", default=None, help="write the per-convolution event timings here")
+    a = ap.parse_args()
+
+    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            sys.exit("launch multi-GPU runs with torch.distributed.run --nproc-per-node N")
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    import sbgm_danra_amd as S
+    from sbgm_danra_amd import _native as N
+    net = build_model(dev)
+    B, HW = a.batch, a.size
+    g = torch.Generator().manual_seed(42 + rank)
+    cond = torch.randn(B, 1, HW, HW, generator=g).to(dev)
+    if not a.no_autotune:
+        net.autotune(B, HW, HW, cond_channels=(0, 0, 1))
+    sampler = S.Euler_Maruyama_sampler if a.sampler == "em" else S.pc_sampler
+    evals_per_step = 1 if a.sampler == "em" else 2
+    kw = dict(batch_size=B, device=dev, img_size=HW, cond_img=cond, use_graph=not a.no_graph, seed=1234 + rank)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # warm-up (untimed): graph capture / instantiate paths, caches, clocks
+    sampler(net, S.marginal_prob_std_fn, S.diffusion_coeff_fn, num_steps=max(2, a.warmup), **kw)
+    barrier()
+    t0 = time.perf_counter()
+    out = sampler(net, S.marginal_prob_std_fn, S.diffusion_coeff_fn, num_steps=a.steps, **kw)
+    barrier()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(out).all()
+    if world > 1:
+        tt = torch.tensor([dt], device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+
+    roof, cpu = None, None
+    if rank == 0:
+        # ---- roofline of the dominant kernel family, HIP events on the launch stream -------------------------------
+        lib = N.lib()
+        x = torch.randn(B, 1, HW, HW, device=dev) * 10
+        t = torch.full((B,), 0.5, device=dev)
+        o = torch.empty_like(x)
+        eng = net._engine(None, None, cond)
+        prof = N.Profile()
+        best = None
+        for _ in range(5):
+            N.check(lib.sbgm_model_profile_forward(eng.h, x.data_ptr(), t.data_ptr(), None, cond.data_ptr(), None, None,
+                                                   o.data_ptr(), B, HW, HW, C.byref(prof),
+                                                   a.profile_csv.encode() if a.profile_csv else None, N.stream()))
+            if best is None or prof.ms_conv < best[0]:
+                best = (prof.ms_conv, prof.flops_conv, prof.n_conv, prof.ms_total_with_events, prof.ms_conv_max,
+                        prof.flops_conv_max)
+        ms_conv, fl_conv, n_conv, ms_tot, ms_max, fl_max = best
+        ach = fl_conv / (ms_conv * 1e-3) * 1e-12
+        ms_eval = dt / (a.steps * evals_per_step) * 1e3
+        flops_eval = FLOP_PER_SAMPLE_128 * B * (HW / 128.0) ** 2
+        roof = {"bound": "mfma", "kernel": "conv_igemm_kernel<KH,KW,S,PAD,FCO,FPX> (fp32 v_mfma_f32_16x16x4_f32), all "
+                                           f"{n_conv} launches of one evaluation",
+                "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS, "traffic": None,
+                "ms_conv_per_eval": ms_conv, "gflop_conv_per_eval": fl_conv * 1e-9,
+                "slowest_launch": {"ms": ms_max, "tflops": fl_max / (ms_max * 1e-3) * 1e-12},
+                "whole_eval": {"ms": ms_eval, "gflop": flops_eval * 1e-9,
+                               "fp32_frac": flops_eval / (ms_eval * 1e-3) / (PEAK_FP32_TFLOPS * 1e12),
+                               "hbm_frac_layer_fused_bytes": BYTES_PER_EVAL(B, HW) / (ms_eval * 1e-3) / (PEAK_HBM_GBS * 1e9)}}
+        if not a.no_cpu_baseline:
+            cpu = cpu_baseline(B, HW)
+
+    if rank == 0:
+        value = B * a.steps * world / dt
+        line = {"metric": "denoising steps/sec (batch x SDE-steps/s) at 128x128", "value": value, "unit": "denoising steps/s",
+                "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"{HW}x{HW} 1-cond->1-target (C_in=2), batch {B}/GPU, VE-SDE "
+                                       f"{'Euler-Maruyama' if a.sampler == 'em' else 'predictor-corrector'} sampling, "
+                                       f"{evals_per_step} network eval/step, hipGraph={'off' if a.no_graph else 'on'}",
+                           "global_batch": B * world, "sampler": a.sampler, "network_evals_per_s": value * evals_per_step,
+                           "parallelism": f"dp{world} (independent batches, no collective)"},
+                "roofline": roof, "cpu_baseline": cpu}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

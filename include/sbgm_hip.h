@@ -99,6 +99,19 @@ int sbgm_sampler_run(sbgm_model* m, const sbgm_sampler_args* a, void* stream);
 /* Conv autotuning: time the tile / split-K candidates of every convolution of the (B,H,W) plan once and keep the
  * fastest.  Synchronises the stream.  Optional; without it a static heuristic is used. */
 int sbgm_model_autotune(sbgm_model* m, int B, int H, int W, void* stream);
+/* Eager forward with each convolution launch bracketed by HIP events on `stream` (synchronises).  csv_path (host
+ * string, may be NULL) receives one line per convolution. */
+typedef struct sbgm_profile {
+    float ms_total_with_events;  /* whole evaluation, including the event records */
+    float ms_conv;               /* sum over implicit-GEMM convolution launches (+ their split-K reduce) */
+    float ms_conv_max;           /* slowest single convolution */
+    double flops_conv;           /* algorithmic FLOPs of those launches (2*M*Cout*K, unpadded K) */
+    double flops_conv_max;
+    int n_conv;
+} sbgm_profile;
+int sbgm_model_profile_forward(sbgm_model* m, const float* x, const float* t, const int64_t* y, const float* cond_img,
+                               const float* lsm_cond, const float* topo_cond, float* out, int B, int H, int W,
+                               sbgm_profile* summary, const char* csv_path, void* stream);
 /* Device time of the last N forwards is not tracked here; bench.py brackets calls with HIP events it gets from: */
 int sbgm_event_create(void** ev);
 int sbgm_event_record(void* ev, void* stream);
@@ -120,7 +133,7 @@ int64_t sbgm_conv_packed_numel(int Cout, int KH, int KW, int c_pad);
 int sbgm_conv_pack_weight(const float* w_oihw, float* packed, int Cout, int Cin, int KH, int KW, int c_pad, void* stream);
 /* nn.Conv2d (+ folded BatchNorm scale/bias, + time bias, + residual, + ReLU) on the fp32 MFMA implicit-GEMM
  * kernel.  score_unet.py:206-219, torchvision BasicBlock convs, :468, :489; nn.Linear as 1x1 (:127-134).
- * tile_co/tile_px/splits = 0 -> heuristic.  ws: split-K scratch (>= splits*M*Cout floats) or NULL if splits<=1. */
+ * tile_co/tile_px/splits/waves_per_tile = 0 -> defaults.  ws: split-K scratch (>= splits*M*Cout floats) or NULL if splits<=1. */
 typedef struct sbgm_conv_args {
     const float* x;          /* [B,H,W,c_pad] */
     const float* w_packed;
@@ -131,9 +144,11 @@ typedef struct sbgm_conv_args {
     const float* residual;   /* [B,OH,OW,Cout] or NULL */
     int B, H, W, c_pad, Cout;
     int KH, KW, stride, pad;
-    int relu;
+    int act;                 /* SBGM_NONE, SBGM_RELU or SBGM_GELU (exact erf), fused into the epilogue */
     int tbias_after_act;
-    int tile_co, tile_px, splits;
+    int tile_co, tile_px;    /* wave tile in 16-element fragments: {2,4} x {1,2,4}; 0 = default */
+    int splits;              /* split-K over the grid (needs ws); 0/1 = off */
+    int waves_per_tile;      /* in-workgroup split-K: 1, 2 or 4 waves share one tile; 0 = 1 */
     float* ws;
     int64_t ws_floats;
 } sbgm_conv_args;
@@ -142,7 +157,7 @@ int sbgm_conv2d_fwd(const sbgm_conv_args* a, void* stream);
 /* nn.Upsample(scale_factor=2, mode="bilinear", align_corners=False).  score_unet.py:467 */
 int sbgm_upsample2x_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream);
 /* nn.GroupNorm / nn.InstanceNorm2d (+ skip add, + time bias, + activation).  score_unet.py:480-483, :585-615.
- * gamma/beta NULL = no affine (InstanceNorm2d default).  stats_ws: >= 24*B*G bytes. */
+ * gamma/beta NULL = no affine (InstanceNorm2d default).  stats_ws: >= 1024*B*G bytes. */
 int sbgm_groupnorm_fwd(const float* x, float* y, const float* gamma, const float* beta, const float* skip,
                        const float* tbias, int act, int B, int HW, int C, int G, float eps, void* stats_ws, void* stream);
 /* nn.LayerNorm(C).  score_unet.py:128-129 */

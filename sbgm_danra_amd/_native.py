@@ -33,11 +33,16 @@ class SamplerArgs(C.Structure):
                 ("topo_cond", _vp), ("noise", _vp), ("out", _vp)]
 
 
+class Profile(C.Structure):
+    _fields_ = [("ms_total_with_events", _f), ("ms_conv", _f), ("ms_conv_max", _f), ("flops_conv", C.c_double),
+                ("flops_conv_max", C.c_double), ("n_conv", _i)]
+
+
 class ConvArgs(C.Structure):
     _fields_ = [("x", _vp), ("w_packed", _vp), ("out", _vp), ("scale", _vp), ("bias", _vp), ("tbias", _vp),
                 ("residual", _vp), ("B", _i), ("H", _i), ("W", _i), ("c_pad", _i), ("Cout", _i), ("KH", _i), ("KW", _i),
-                ("stride", _i), ("pad", _i), ("relu", _i), ("tbias_after_act", _i), ("tile_co", _i), ("tile_px", _i),
-                ("splits", _i), ("ws", _vp), ("ws_floats", _i64)]
+                ("stride", _i), ("pad", _i), ("act", _i), ("tbias_after_act", _i), ("tile_co", _i), ("tile_px", _i),
+                ("splits", _i), ("waves_per_tile", _i), ("ws", _vp), ("ws_floats", _i64)]
 
 
 # name -> (restype, argtypes); every symbol include/sbgm_hip.h declares
@@ -55,6 +60,7 @@ SIGNATURES = {
     "sbgm_model_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp), _i, _i, _i, _i, _vp]),
     "sbgm_sampler_run": (_i, [_vp, C.POINTER(SamplerArgs), _vp]),
     "sbgm_model_autotune": (_i, [_vp, _i, _i, _i, _vp]),
+    "sbgm_model_profile_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, C.POINTER(Profile), C.c_char_p, _vp]),
     "sbgm_event_create": (_i, [C.POINTER(_vp)]),
     "sbgm_event_record": (_i, [_vp, _vp]),
     "sbgm_event_elapsed_ms": (_i, [_vp, _vp, C.POINTER(_f)]),

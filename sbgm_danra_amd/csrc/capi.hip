@@ -34,9 +34,11 @@ int sbgm_conv2d_fwd(const sbgm_conv_args* a, void* stream) {
     ConvParams p{};
     p.x = a->x; p.wp = a->w_packed; p.out = a->out; p.scale = a->scale; p.bias = a->bias; p.tbias = a->tbias;
     p.res = a->residual; p.B = a->B; p.H = a->H; p.W = a->W; p.Cs = a->c_pad; p.Cout = a->Cout;
-    p.act = a->relu ? SBGM_ACT_RELU : SBGM_ACT_NONE;
+    p.act = a->act;
+    SBGM_CHECK(a->act == SBGM_NONE || a->act == SBGM_RELU || a->act == SBGM_GELU, "conv2d: act must be none, relu or gelu");
     p.tbias_after_act = a->tbias_after_act;
-    ConvTile t{a->tile_co ? a->tile_co : (a->Cout % 64 == 0 ? 4 : 2), a->tile_px ? a->tile_px : 2, a->splits ? a->splits : 1};
+    ConvTile t{a->tile_co ? a->tile_co : (a->Cout % 64 == 0 ? 4 : 2), a->tile_px ? a->tile_px : 2, a->splits ? a->splits : 1,
+               a->waves_per_tile ? a->waves_per_tile : 1};
     SBGM_CHECK(a->Cout % 32 == 0, "conv2d: Cout=%d must be a multiple of 32", a->Cout);
     if (t.splits > 1) {
         const int OH = (a->H + 2 * a->pad - a->KH) / a->stride + 1, OW = (a->W + 2 * a->pad - a->KW) / a->stride + 1;

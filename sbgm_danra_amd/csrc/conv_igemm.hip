@@ -15,7 +15,10 @@
 // a lane issues FCO + FPX 16-byte buffer loads (hardware bounds check supplies the zero padding) and
 // 4*FCO*FPX MFMAs; the next step's operands are prefetched into a second register set.  Tiles are mapped to
 // workgroups so that an XCD owns a contiguous range of (co-tile, px-tile) pairs (weights stay in its L2).
-// Small-M layers are filled with split-K over gridDim.y followed by splitk_reduce_epilogue.
+// Small-M layers are filled two ways: WS waves of a workgroup split the K range of ONE tile and combine their
+// accumulators through LDS before the epilogue (in-workgroup split-K: more waves per SIMD to hide the operand
+// latency, no extra launch, no global traffic), and, for the tiniest layers, split-K over gridDim.y followed by
+// splitk_reduce_epilogue.
 #include "common.h"
 #include "kernels.h"
 
@@ -32,8 +35,31 @@ struct PixLane {      // per-lane decode of the output pixel this lane gathers f
     int y0, x0;       // oy*S - PAD, ox*S - PAD
 };
 
-template <int KH, int KW, int S, int PAD, int FCO, int FPX, int CMODE>
+__device__ __noinline__ f32x4 gelu4(f32x4 v) {      // rare (attention FF only): keep the erf expansion out of line
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = sbgm_act(v[e], SBGM_ACT_GELU);
+    return v;
+}
+
+// scale/bias (folded BN or conv bias) -> early time bias -> residual -> activation -> late time bias
+__device__ __forceinline__ f32x4 conv_epilogue(f32x4 v, const ConvParams& p, int co, size_t m, int b) {
+    if (p.scale) v *= *reinterpret_cast<const f32x4*>(p.scale + co);
+    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + co);
+    if (p.tbias && !p.tbias_after_act) v += *reinterpret_cast<const f32x4*>(p.tbias + (size_t)b * p.Cout + co);
+    if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + m * p.Cout + co);
+    if (p.act == SBGM_ACT_RELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    } else if (p.act == SBGM_ACT_GELU) {
+        v = gelu4(v);
+    }
+    if (p.tbias && p.tbias_after_act) v += *reinterpret_cast<const f32x4*>(p.tbias + (size_t)b * p.Cout + co);
+    return v;
+}
+
+template <int KH, int KW, int S, int PAD, int FCO, int FPX, int CMODE, int WS>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r16 = lane & 15;     // row (co) for the A fragment, column (pixel) for the B fragment
@@ -43,8 +69,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     const int nb = gridDim.x, bid = blockIdx.x;
     const int q = nb >> 3, r = nb & 7, xcd = bid & 7, idx = bid >> 3;
     const int lb = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    const int tile = lb * 4 + wave;
-    if (tile >= p.n_px_tiles * p.n_co_tiles) return;
+    constexpr int TPW = 4 / WS;                     // tiles per workgroup
+    const int tslot = wave / WS, kpart = wave - tslot * WS;
+    const int tile_raw = lb * TPW + tslot;
+    const bool tile_ok = tile_raw < p.n_px_tiles * p.n_co_tiles;
+    if (WS == 1 && !tile_ok) return;                // no barrier below in that configuration
+    const int tile = tile_ok ? tile_raw : 0;
     const int co_tile = tile / p.n_px_tiles;
     const int px_tile = tile - co_tile * p.n_px_tiles;
     const int co0 = co_tile * (16 * FCO);
@@ -75,8 +105,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     }
 
     // ---- K range of this split ---------------------------------------------------------------------
-    const int s_begin = blockIdx.y * p.steps_per_split;
-    const int s_end = min(p.nsteps, s_begin + p.steps_per_split);
+    int s_begin = blockIdx.y * p.steps_per_split;
+    int s_end = min(p.nsteps, s_begin + p.steps_per_split);
+    if (WS > 1) {                                   // this wave's share of the split's K range
+        const int len = s_end - s_begin, per = (len + WS - 1) / WS;
+        s_begin = s_begin + kpart * per;
+        s_end = min(s_end, s_begin + per);
+        if (!tile_ok) s_end = s_begin;
+    }
 
     const uint32_t w_lane_off = (uint32_t)((co0 + r16) * 16 + kq * 4) * 4u;
     const uint32_t w_step_stride = (uint32_t)p.Cout * 64u;   // bytes per K step: Cout rows x 16 floats
@@ -155,6 +191,29 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         if (s < s_end) compute(f0);
     }
 
+    // ---- in-workgroup split-K: waves 1..WS-1 of a tile hand their accumulators to wave 0 through LDS --------------
+    if (WS > 1) {
+        f32x4* red = reinterpret_cast<f32x4*>(smem_raw);      // [tslot][kpart-1][frag][lane]
+        constexpr int NF = FCO * FPX;
+        if (kpart > 0) {
+            f32x4* dst = red + ((tslot * (WS - 1) + (kpart - 1)) * NF) * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < FCO; ++i)
+#pragma unroll
+                for (int j = 0; j < FPX; ++j) dst[(i * FPX + j) * 64] = acc[i][j];
+        }
+        __syncthreads();
+        if (kpart > 0 || !tile_ok) return;
+#pragma unroll
+        for (int k = 0; k < WS - 1; ++k) {
+            const f32x4* src = red + ((tslot * (WS - 1) + k) * NF) * 64 + lane;
+#pragma unroll
+            for (int i = 0; i < FCO; ++i)
+#pragma unroll
+                for (int j = 0; j < FPX; ++j) acc[i][j] += src[(i * FPX + j) * 64];
+        }
+    }
+
     // ---- epilogue: lane owns channels co0+16i+4kq..+3 of pixel m0+16j+r16 ------------------------------
     const bool partial = gridDim.y > 1;
     float* outp = p.out + (partial ? (size_t)blockIdx.y * (size_t)p.M * p.Cout : 0);
@@ -167,17 +226,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         for (int i = 0; i < FCO; ++i) {
             const int co = co0 + 16 * i + 4 * kq;
             f32x4 v = acc[i][j];
-            if (!partial) {
-                if (p.scale) v *= *reinterpret_cast<const f32x4*>(p.scale + co);
-                if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + co);
-                if (p.tbias && !p.tbias_after_act) v += *reinterpret_cast<const f32x4*>(p.tbias + (size_t)b * p.Cout + co);
-                if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)m * p.Cout + co);
-                if (p.act == SBGM_ACT_RELU) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-                }
-                if (p.tbias && p.tbias_after_act) v += *reinterpret_cast<const f32x4*>(p.tbias + (size_t)b * p.Cout + co);
-            }
+            if (!partial) v = conv_epilogue(v, p, co, (size_t)m, b);
             *reinterpret_cast<f32x4*>(outp + (size_t)m * p.Cout + co) = v;
         }
     }
@@ -195,16 +244,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_epilogue(const ConvParams p
         const int m = (int)(e / p.Cout);
         const int co = (int)(e - (size_t)m * p.Cout);
         const int b = m / ohw;
-        if (p.scale) v *= *reinterpret_cast<const f32x4*>(p.scale + co);
-        if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + co);
-        if (p.tbias && !p.tbias_after_act) v += *reinterpret_cast<const f32x4*>(p.tbias + (size_t)b * p.Cout + co);
-        if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + e);
-        if (p.act == SBGM_ACT_RELU) {
-#pragma unroll
-            for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
-        }
-        if (p.tbias && p.tbias_after_act) v += *reinterpret_cast<const f32x4*>(p.tbias + (size_t)b * p.Cout + co);
-        *reinterpret_cast<f32x4*>(p.out + e) = v;
+        *reinterpret_cast<f32x4*>(p.out + e) = conv_epilogue(v, p, co, (size_t)m, b);
     }
 }
 
@@ -233,13 +273,16 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __re
 }
 
 template <int KH, int KW, int S, int PAD, int CMODE>
-int launch_geom(const ConvParams& p, int fco, int fpx, dim3 grid, hipStream_t st) {
-#define SBGM_TILE(FC, FP)                                                                   \
-    if (fco == FC && fpx == FP) {                                                           \
-        hipLaunchKernelGGL((conv_igemm_kernel<KH, KW, S, PAD, FC, FP, CMODE>), grid, dim3(256), 0, st, p); \
-        return 0;                                                                           \
+int launch_geom(const ConvParams& p, const ConvTile& t, dim3 grid, hipStream_t st) {
+#define SBGM_TILE(FC, FP, W)                                                                                  \
+    if (t.fco == FC && t.fpx == FP && t.ws == W) {                                                            \
+        const size_t lds = W > 1 ? (size_t)(4 / W) * (W - 1) * FC * FP * 64 * 16 : 0;                          \
+        hipLaunchKernelGGL((conv_igemm_kernel<KH, KW, S, PAD, FC, FP, CMODE, W>), grid, dim3(256), lds, st, p); \
+        return 0;                                                                                             \
     }
-    SBGM_TILE(4, 4) SBGM_TILE(4, 2) SBGM_TILE(4, 1) SBGM_TILE(2, 4) SBGM_TILE(2, 2) SBGM_TILE(2, 1)
+#define SBGM_TILES(W) SBGM_TILE(4, 4, W) SBGM_TILE(4, 2, W) SBGM_TILE(4, 1, W) SBGM_TILE(2, 4, W) SBGM_TILE(2, 2, W) SBGM_TILE(2, 1, W)
+    SBGM_TILES(1) SBGM_TILES(2) SBGM_TILES(4)
+#undef SBGM_TILES
 #undef SBGM_TILE
     return 1;
 }
@@ -269,7 +312,8 @@ int sbgm_launch_pack_conv_weight(const float* w_oihw, float* wp, int Cout, int C
 int sbgm_launch_conv(const ConvGeom& g, ConvParams p, const ConvTile& cfg, float* partial_ws, hipStream_t st) {
     SBGM_CHECK(p.Cout % (16 * cfg.fco) == 0, "conv: Cout=%d not a multiple of the %d-row tile", p.Cout, 16 * cfg.fco);
     SBGM_CHECK(p.Cs == 4 || p.Cs == 8 || p.Cs % 16 == 0, "conv: padded Cin %d unsupported", p.Cs);
-    SBGM_CHECK(p.act == SBGM_ACT_NONE || p.act == SBGM_ACT_RELU, "conv: only none/relu fuse into the epilogue (act=%d)", p.act);
+    SBGM_CHECK(p.act == SBGM_ACT_NONE || p.act == SBGM_ACT_RELU || p.act == SBGM_ACT_GELU, "conv: act=%d does not fuse into the epilogue", p.act);
+    SBGM_CHECK(cfg.ws == 1 || cfg.ws == 2 || cfg.ws == 4, "conv: waves-per-tile %d must be 1, 2 or 4", cfg.ws);
     SBGM_CHECK((size_t)p.B * p.H * p.W * p.Cs * 4 < (1ull << 31), "conv: input tensor exceeds 2 GiB buffer window");
     p.OH = (p.H + 2 * g.pad - g.kh) / g.stride + 1;
     p.OW = (p.W + 2 * g.pad - g.kw) / g.stride + 1;
@@ -284,7 +328,8 @@ int sbgm_launch_conv(const ConvGeom& g, ConvParams p, const ConvTile& cfg, float
     p.x_bytes = (uint32_t)((size_t)p.B * p.H * p.W * p.Cs * 4);
     p.w_bytes = (uint32_t)((size_t)p.nsteps * p.Cout * 64);
     const int ntiles = p.n_px_tiles * p.n_co_tiles;
-    dim3 grid((ntiles + 3) / 4, real_splits);
+    const int tpw = 4 / cfg.ws;
+    dim3 grid((ntiles + tpw - 1) / tpw, real_splits);
     float* final_out = p.out;
     if (real_splits > 1) {
         SBGM_CHECK(partial_ws != nullptr, "conv: split-K needs a partial workspace");
@@ -294,12 +339,12 @@ int sbgm_launch_conv(const ConvGeom& g, ConvParams p, const ConvTile& cfg, float
     int rc = 1;
 #define SBGM_GEOM(KH_, KW_, S_, PAD_, CM_)                                                        \
     if (g.kh == KH_ && g.kw == KW_ && g.stride == S_ && g.pad == PAD_ && cmode == CM_)            \
-        rc = launch_geom<KH_, KW_, S_, PAD_, CM_>(p, cfg.fco, cfg.fpx, grid, st);
+        rc = launch_geom<KH_, KW_, S_, PAD_, CM_>(p, cfg, grid, st);
     SBGM_GEOM(8, 8, 2, 3, 0) SBGM_GEOM(8, 8, 2, 3, 4) SBGM_GEOM(8, 8, 2, 3, 8)
     SBGM_GEOM(3, 3, 1, 1, 0) SBGM_GEOM(3, 3, 2, 1, 0) SBGM_GEOM(1, 1, 2, 0, 0) SBGM_GEOM(1, 1, 1, 0, 0)
 #undef SBGM_GEOM
-    SBGM_CHECK(rc == 0, "conv: no kernel for k=%dx%d s=%d p=%d cs=%d tile=%dx%d", g.kh, g.kw, g.stride, g.pad, p.Cs,
-               cfg.fco, cfg.fpx);
+    SBGM_CHECK(rc == 0, "conv: no kernel for k=%dx%d s=%d p=%d cs=%d tile=%dx%d ws=%d", g.kh, g.kw, g.stride, g.pad, p.Cs,
+               cfg.fco, cfg.fpx, cfg.ws);
     SBGM_LAUNCH_CHECK();
     if (real_splits > 1) {
         p.out = final_out;

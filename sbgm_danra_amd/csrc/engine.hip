@@ -4,6 +4,7 @@
 // :559-627 (DecoderBlock.forward), :733-758 (Decoder.forward), :829-879 (ScoreNet.forward) and
 // sbgm/score_sampling.py:63-127 / :136-230.
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -75,6 +76,8 @@ struct sbgm_model {
     int table_cap = 0;
     std::map<ConvOpKey, ConvTile> tuned;
     bool tuning = false;
+    struct ConvRec { ConvGeom g; int B, H, W, Cs, Cout, M, nsteps; ConvTile t; double flops; hipEvent_t e0, e1; float ms; };
+    std::vector<ConvRec>* prof = nullptr;   // when set, conv() brackets every launch with events
     hipStream_t graph_stream = nullptr;     // private capture stream (the caller's may be the legacy default stream)
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
 
@@ -313,19 +316,20 @@ ConvTile sbgm_model::pick_tile(const ConvGeom& g, const ConvParams& p) {
     if (it != tuned.end()) return it->second;
     const int M = p.B * OH * OW;
     const int nsteps = sbgm_conv_nsteps(g.kh, g.kw, p.Cs);
-    const int target = 2048;
-    const int cand[4][2] = {{4, 4}, {4, 2}, {2, 2}, {2, 1}};
+    const int target = 2048;                 // ~2 waves per SIMD
+    const int cand[3][2] = {{4, 4}, {4, 2}, {2, 2}};
     for (auto& c : cand) {
         if (p.Cout % (16 * c[0])) continue;
         const long tiles = (long)((M + 16 * c[1] - 1) / (16 * c[1])) * (p.Cout / (16 * c[0]));
-        if (tiles >= target) return ConvTile{c[0], c[1], 1};
+        for (int ws : {1, 2, 4})
+            if (tiles * ws >= target && nsteps / ws >= 2) return ConvTile{c[0], c[1], 1, ws};
     }
-    // small problem: 64x32 tiles + split-K (>= 4 K-steps per split)
-    int fco = p.Cout % 64 == 0 ? 4 : 2, fpx = 2;
-    long tiles = (long)((M + 16 * fpx - 1) / (16 * fpx)) * (p.Cout / (16 * fco));
-    if (tiles * (nsteps / 4) < target / 2) { fpx = 1; tiles = (long)((M + 15) / 16) * (p.Cout / (16 * fco)); }
-    int splits = (int)std::min<long>(std::max<long>(1, target / std::max<long>(1, tiles)), std::max(1, nsteps / 4));
-    return ConvTile{fco, fpx, splits};
+    // tiny problem: 64x32 (or 32x32) tiles, 4 waves per tile, plus split-K over the grid (>= 2 K-steps per wave)
+    const int fco = p.Cout % 64 == 0 ? 4 : 2, fpx = 2;
+    const long tiles = (long)((M + 16 * fpx - 1) / (16 * fpx)) * (p.Cout / (16 * fco));
+    const int ws = nsteps >= 8 ? 4 : nsteps >= 4 ? 2 : 1;
+    const int splits = (int)std::min<long>(std::max<long>(1, target / std::max<long>(1, tiles * ws)), std::max(1, nsteps / (2 * ws)));
+    return ConvTile{fco, fpx, splits, ws};
 }
 
 int sbgm_model::conv(const ConvGeom& g, ConvParams p, hipStream_t st) {
@@ -340,11 +344,13 @@ int sbgm_model::conv(const ConvGeom& g, ConvParams p, hipStream_t st) {
             const int tiles[6][2] = {{4, 4}, {4, 2}, {4, 1}, {2, 4}, {2, 2}, {2, 1}};
             for (auto& t : tiles) {
                 if (p.Cout % (16 * t[0])) continue;
-                for (int sp : {1, 2, 3, 4, 6, 8, 12, 16, 24, 32}) {
-                    if (sp > 1 && nsteps / sp < 2) continue;
-                    const long ntile = (long)(((size_t)p.B * OH * OW + 16 * t[1] - 1) / (16 * t[1])) * (p.Cout / (16 * t[0]));
-                    if (sp > 1 && ntile * sp > 16384) continue;      // pointless: already far more waves than SIMDs
-                    cands.push_back(ConvTile{t[0], t[1], sp});
+                const long ntile = (long)(((size_t)p.B * OH * OW + 16 * t[1] - 1) / (16 * t[1])) * (p.Cout / (16 * t[0]));
+                for (int ws : {1, 2, 4}) {
+                    if (ws > 1 && (nsteps / ws < 2 || ntile * ws > 32768)) continue;
+                    for (int sp : {1, 2, 4, 8, 16}) {
+                        if (sp > 1 && (nsteps / (sp * ws) < 2 || ntile * ws >= 4096)) continue;   // already enough waves
+                        cands.push_back(ConvTile{t[0], t[1], sp, ws});
+                    }
                 }
             }
             hipEvent_t e0, e1;
@@ -371,7 +377,18 @@ int sbgm_model::conv(const ConvGeom& g, ConvParams p, hipStream_t st) {
     }
     ConvTile ct = pick_tile(g, p);
     if (ct.splits > 1 && mc * ct.splits > PARTIAL_FLOATS) ct.splits = (int)std::max<size_t>(1, PARTIAL_FLOATS / mc);
-    return sbgm_launch_conv(g, p, ct, partial, st);
+    if (!prof) return sbgm_launch_conv(g, p, ct, partial, st);
+    ConvRec r{g, p.B, p.H, p.W, p.Cs, p.Cout, p.B * OH * OW, sbgm_conv_nsteps(g.kh, g.kw, p.Cs), ct, 0.0, nullptr, nullptr, 0.f};
+    // algorithmic FLOPs: 2 * M * Cout * (KH*KW*Cin_real); Cs may be padded (only the stem conv), count real K there
+    const int cin_real = (g.kh == 8 && p.Cs <= 16) ? cin_total : p.Cs;
+    r.flops = 2.0 * r.M * p.Cout * (double)(g.kh * g.kw * cin_real);
+    SBGM_HIP(hipEventCreate(&r.e0));
+    SBGM_HIP(hipEventCreate(&r.e1));
+    SBGM_HIP(hipEventRecord(r.e0, st));
+    const int rc = sbgm_launch_conv(g, p, ct, partial, st);
+    SBGM_HIP(hipEventRecord(r.e1, st));
+    prof->push_back(r);
+    return rc;
 }
 
 // y = h + FF(LN2(h)),  h = x + MHA(LN1(x))   over tokens [B*S, C]  (score_unet.py:136-148); in place on x
@@ -397,10 +414,9 @@ int sbgm_model::attention(const AttnW& a, float* x, int B, int S, hipStream_t st
     p.x = att; p.wp = a.outw->dev; p.out = h; p.bias = a.outb->dev; p.Cout = C; p.res = x;
     if (conv(lin, p, st)) return 1;
     if (sbgm_launch_layernorm(h, n1, a.ln2g->dev, a.ln2b->dev, M, C, LN_EPS, st)) return 1;
-    p.x = n1; p.wp = a.f1w->dev; p.out = f1; p.bias = a.f1b->dev; p.res = nullptr;
+    p.x = n1; p.wp = a.f1w->dev; p.out = f1; p.bias = a.f1b->dev; p.res = nullptr; p.act = SBGM_ACT_GELU;   // :131-132
     if (conv(lin, p, st)) return 1;
-    if (sbgm_launch_act(f1, (size_t)M * C, SBGM_ACT_GELU, st)) return 1;
-    p.x = f1; p.wp = a.f2w->dev; p.out = x; p.bias = a.f2b->dev; p.res = h;
+    p.x = f1; p.wp = a.f2w->dev; p.out = x; p.bias = a.f2b->dev; p.res = h; p.act = SBGM_ACT_NONE;
     return conv(lin, p, st);
 }
 
@@ -453,9 +469,9 @@ int sbgm_model::forward(const float* x, const float* t, const int64_t* y, const 
     }
     if (sbgm_launch_time_embed(te, st)) return 1;
 
-    // 24 B per statistic: B*G for GroupNorm (G = C for InstanceNorm), C for BatchNorm
-    const size_t n_stats = std::max<size_t>(512, (size_t)B * (cfg.decoder_norm == SBGM_NORM_GROUP ? std::min(cfg.gn_groups, 512) : 512));
-    double* stats = reinterpret_cast<double*>(wsalloc(n_stats * 6));
+    // GroupNorm: 64 chunks x B x G x 2 doubles (G = C <= 512 for InstanceNorm); BatchNorm: 24 B x C
+    const size_t n_groups = (size_t)B * (cfg.decoder_norm == SBGM_NORM_GROUP ? std::min(cfg.gn_groups, 512) : 512);
+    double* stats = reinterpret_cast<double*>(wsalloc(std::max<size_t>(6 * 512, n_groups * 64 * 4)));
     if (!stats) return 1;
 
     // conv + BatchNorm (+res, relu, late time bias): eval folds BN into the conv epilogue, train runs it after
@@ -788,6 +804,49 @@ int sbgm_model_autotune(sbgm_model* m, int B, int H, int W, void* stream) {
     m->ws_bytes = saved;
     SBGM_HIP(hipStreamSynchronize(st));
     return rc;
+}
+
+// Eager forward with every convolution launch bracketed by HIP events on `stream`.  Fills the summary and, when
+// csv_path is non-null, writes one line per convolution (geometry, tile, split-K, ms, TFLOP/s).
+int sbgm_model_profile_forward(sbgm_model* m, const float* x, const float* t, const int64_t* y, const float* cond_img,
+                               const float* lsm_cond, const float* topo_cond, float* out, int B, int H, int W,
+                               sbgm_profile* summary, const char* csv_path, void* stream) {
+    hipStream_t st = (hipStream_t)stream;
+    if (m->ensure_ws(m->ws_need(B, H, W))) return 1;
+    std::vector<sbgm_model::ConvRec> recs;
+    hipEvent_t t0, t1;
+    SBGM_HIP(hipEventCreate(&t0));
+    SBGM_HIP(hipEventCreate(&t1));
+    m->prof = &recs;
+    SBGM_HIP(hipEventRecord(t0, st));
+    const int rc = m->forward(x, t, y, cond_img, lsm_cond, topo_cond, out, nullptr, B, H, W, 0, st);
+    SBGM_HIP(hipEventRecord(t1, st));
+    m->prof = nullptr;
+    if (rc) return rc;
+    SBGM_HIP(hipEventSynchronize(t1));
+    sbgm_profile s{};
+    SBGM_HIP(hipEventElapsedTime(&s.ms_total_with_events, t0, t1));
+    FILE* f = csv_path ? fopen(csv_path, "w") : nullptr;
+    if (f) fprintf(f, "idx,kh,kw,stride,B,H,W,Cin_pad,Cout,M,ksteps,tile_co,tile_px,splits,ws,gflop,ms,tflops\n");
+    int i = 0;
+    for (auto& r : recs) {
+        SBGM_HIP(hipEventElapsedTime(&r.ms, r.e0, r.e1));
+        (void)hipEventDestroy(r.e0);
+        (void)hipEventDestroy(r.e1);
+        s.ms_conv += r.ms;
+        s.flops_conv += r.flops;
+        s.n_conv += 1;
+        if (r.ms > s.ms_conv_max) { s.ms_conv_max = r.ms; s.flops_conv_max = r.flops; }
+        if (f) fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%.4f,%.4f,%.2f\n", i, r.g.kh, r.g.kw, r.g.stride, r.B, r.H, r.W,
+                       r.Cs, r.Cout, r.M, r.nsteps, 16 * r.t.fco, 16 * r.t.fpx, r.t.splits, r.t.ws, r.flops * 1e-9, r.ms,
+                       r.flops / (r.ms * 1e-3) * 1e-12);
+        ++i;
+    }
+    if (f) fclose(f);
+    (void)hipEventDestroy(t0);
+    (void)hipEventDestroy(t1);
+    if (summary) *summary = s;
+    return 0;
 }
 
 int sbgm_event_create(void** ev) { hipEvent_t e; SBGM_HIP(hipEventCreate(&e)); *ev = e; return 0; }

@@ -9,7 +9,9 @@ struct ConvGeom {
     int kh, kw, stride, pad;
 };
 struct ConvTile {
-    int fco, fpx, splits;   // wave tile = (16*fco) output channels x (16*fpx) pixels; split-K factor
+    int fco, fpx;   // wave tile = (16*fco) output channels x (16*fpx) pixels
+    int splits;     // split-K over gridDim.y (partials + reduce kernel)
+    int ws;         // waves of a workgroup cooperating on one tile (in-workgroup split-K through LDS): 1, 2 or 4
 };
 struct ConvParams {
     const float* x;       // NHWC [B][H][W][Cs]
@@ -70,8 +72,8 @@ int sbgm_launch_conv3x3_cout1(const float* x, const float* w_tap_c, const float*
 int sbgm_launch_pack_cout1_weight(const float* w_oihw, float* w_tap_c, int C, hipStream_t st);
 
 // ---- norm.hip ------------------------------------------------------------------------------------------
-// GroupNorm / InstanceNorm over NHWC.  stats_ws: 2*B*G doubles followed by 2*B*G floats (24 B per statistic;
-// for batchnorm B*G -> C).  Zeroed by the launcher.
+// GroupNorm / InstanceNorm over NHWC.  stats_ws: groupnorm needs 16*64*B*G bytes (partial sums per pixel chunk);
+// batchnorm needs 24*C bytes (zeroed by the launcher).
 int sbgm_launch_groupnorm(const float* x, float* y, const float* gamma, const float* beta, const float* skip,
                           const float* tbias, int act, int B, int HW, int C, int G, float eps, double* stats_ws,
                           hipStream_t st);

@@ -72,36 +72,92 @@ __global__ void norm_finalize_kernel(const double* __restrict__ stats, float* __
     }
 }
 
+// ---- GroupNorm pass 1: partial sums per (sample, chunk, group) -> stats[b][chunk][g][2] (doubles) -------------------
+constexpr int GN_MAX_CHUNKS = 64;
+__global__ __launch_bounds__(NORM_THREADS) void gn_partial_kernel(const float* __restrict__ x, double* __restrict__ stats,
+                                                                  int HW, int C, int G, int px_per_block) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    double* ssum = reinterpret_cast<double*>(smem_raw);   // [C]
+    double* ssq = ssum + C;                               // [C]
+    const int cq = C >> 2;
+    const int b = blockIdx.y;
+    for (int c = threadIdx.x; c < 2 * C; c += NORM_THREADS) ssum[c] = 0.0;
+    __syncthreads();
+    const int q = threadIdx.x % cq;
+    const int lanes_px = NORM_THREADS / cq;
+    const int stripe = threadIdx.x / cq;
+    const int p_begin = blockIdx.x * px_per_block;
+    const int p_end = min(HW, p_begin + px_per_block);
+    if (stripe < lanes_px) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+        const float* base = x + (size_t)b * HW * C + q * 4;
+        for (int p = p_begin + stripe; p < p_end; p += lanes_px) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)p * C);
+            s += v;
+            s2 += v * v;
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            atomicAdd(&ssum[q * 4 + e], (double)s[e]);      // ds_add_f64
+            atomicAdd(&ssq[q * 4 + e], (double)s2[e]);
+        }
+    }
+    __syncthreads();
+    const int cpg = C / G;
+    for (int g = threadIdx.x; g < G; g += NORM_THREADS) {
+        double a = 0.0, a2 = 0.0;
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) { a += ssum[c]; a2 += ssq[c]; }
+        double* o = stats + (((size_t)b * gridDim.x + blockIdx.x) * G + g) * 2;
+        o[0] = a;
+        o[1] = a2;
+    }
+}
+
 // ---- K18 + K21 + K12 + K20: y = act( GN(x) * gamma + beta  [+ skip] [+ tbias[b]] ) ---------------------------
-// reference score_unet.py:585/592 (norms), :600 (skip add), :612 (time add), :615 (activation)
+// reference score_unet.py:585/592 (norms), :600 (skip add), :612 (time add), :615 (activation).  Grid (blocks, B).
 __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                               const float* __restrict__ gamma,
                                                               const float* __restrict__ beta,
                                                               const float* __restrict__ skip,
-                                                              const float* __restrict__ tbias, int act, int B, int HW,
-                                                              int C, int G, const float* __restrict__ mr) {
+                                                              const float* __restrict__ tbias, int act, int HW, int C,
+                                                              int G, int chunks, float eps,
+                                                              const double* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* mr = reinterpret_cast<float*>(smem_raw);        // [G][2] mean, rstd
+    const int b = blockIdx.y;
     const int cq = C >> 2, cpg = C / G;
-    const size_t total = (size_t)B * HW * cq;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int q = (int)(i % cq);
-        const int b = (int)(i / ((size_t)cq * HW));
-        const int c = q * 4;
-        f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+        double a = 0.0, a2 = 0.0;
+        const double* sp = stats + ((size_t)b * chunks * G + g) * 2;
+        for (int c = 0; c < chunks; ++c) { a += sp[(size_t)c * G * 2]; a2 += sp[(size_t)c * G * 2 + 1]; }
+        const double inv_n = 1.0 / ((double)HW * cpg);
+        const double mean = a * inv_n;
+        const double var = fmax(a2 * inv_n - mean * mean, 0.0);
+        mr[2 * g] = (float)mean;
+        mr[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    const size_t per_sample = (size_t)HW * cq;
+    const f32x4* xb = reinterpret_cast<const f32x4*>(x) + (size_t)b * per_sample;
+    const f32x4* sb = skip ? reinterpret_cast<const f32x4*>(skip) + (size_t)b * per_sample : nullptr;
+    f32x4* yb = reinterpret_cast<f32x4*>(y) + (size_t)b * per_sample;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_sample; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cq) * 4;
+        f32x4 v = xb[i];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int g = (c + e) / cpg;
-            const float mean = mr[((size_t)b * G + g) * 2], rstd = mr[((size_t)b * G + g) * 2 + 1];
-            float o = (v[e] - mean) * rstd;
+            float o = (v[e] - mr[2 * g]) * mr[2 * g + 1];
             if (gamma) o = o * gamma[c + e] + beta[c + e];
             v[e] = o;
         }
-        if (skip) v += reinterpret_cast<const f32x4*>(skip)[i];
+        if (sb) v += sb[i];
         if (tbias) v += *reinterpret_cast<const f32x4*>(tbias + (size_t)b * C + c);
         if (act != SBGM_ACT_NONE) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = sbgm_act(v[e], act);
         }
-        reinterpret_cast<f32x4*>(y)[i] = v;
+        yb[i] = v;
     }
 }
 
@@ -186,21 +242,19 @@ int sbgm_launch_groupnorm(const float* x, float* y, const float* gamma, const fl
                           hipStream_t st) {
     SBGM_CHECK(C % 4 == 0 && C <= 1024 && C % G == 0, "groupnorm: C=%d G=%d unsupported", C, G);
     SBGM_CHECK((gamma == nullptr) == (beta == nullptr), "groupnorm: gamma and beta must both be set or both null");
-    SBGM_HIP(hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * (size_t)B * G, st));
-    // ~64 pixels per stripe-thread keeps the fp32 partials short; at least 1 chunk, at most 256 per sample
+    // pass 1: per-(sample, pixel-chunk, group) partial sums, plain stores (no zeroing, no atomics, deterministic);
+    // pass 2: every apply block re-reduces its sample's <= GN_MAX_CHUNKS partials into LDS, then streams.
     const int lanes_px = std::max(1, NORM_THREADS / (C / 4));
-    int chunks = std::max(1, std::min(256, HW / (lanes_px * 32)));
+    int chunks = std::max(1, std::min(GN_MAX_CHUNKS, HW / (lanes_px * 16)));
     const int ppb = (HW + chunks - 1) / chunks;
     chunks = (HW + ppb - 1) / ppb;
-    hipLaunchKernelGGL(norm_stats_kernel<false>, dim3(chunks, B), dim3(NORM_THREADS), 2 * C * sizeof(double), st, x,
-                       stats_ws, HW, C, G, ppb);
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, B), dim3(NORM_THREADS), 2 * C * sizeof(double), st, x, stats_ws, HW, C,
+                       G, ppb);
     SBGM_LAUNCH_CHECK();
-    float* mr = reinterpret_cast<float*>(stats_ws + 2 * (size_t)B * G);
-    hipLaunchKernelGGL(norm_finalize_kernel, dim3((B * G + 255) / 256), dim3(256), 0, st, stats_ws, mr, B * G,
-                       1.0 / ((double)HW * (C / G)), eps);
-    SBGM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(stream_blocks((size_t)B * HW * (C / 4))), dim3(256), 0, st, x, y, gamma,
-                       beta, skip, tbias, act, B, HW, C, G, mr);
+    const size_t per_sample = (size_t)HW * (C / 4);
+    const int bx = (int)std::max<size_t>(1, std::min<size_t>((per_sample + 255) / 256, 2048 / std::max(1, B) + 1));
+    hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(bx, B), dim3(256), 2 * G * sizeof(float), st, x, y, gamma, beta, skip, tbias,
+                       act, HW, C, G, chunks, eps, stats_ws);
     SBGM_LAUNCH_CHECK();
     return 0;
 }

@@ -123,78 +123,108 @@ __global__ __launch_bounds__(256) void time_embed_kernel(TimeEmbedArgs a) {
     }
 }
 
-// ---- K2: all time projections of one forward in one launch; one wave per output element --------------
-__global__ __launch_bounds__(256) void time_proj_kernel(TimeEmbedArgs a, int total_out) {
+// ---- K2: all time projections of one forward in one launch ---------------------------------------------------------
+// One wave per (projection, output channel): the weight row stays in registers and is dotted with every sample's
+// embedding (the embeddings are tiny and L2-resident), so the 1.5 MB of projection weights are read once per launch.
+__global__ __launch_bounds__(256) void time_proj_kernel(TimeEmbedArgs a, int total_ch) {
     const int lane = threadIdx.x & 63;
     const int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (wid >= total_out) return;
-    int rem = wid, pi = 0;
+    if (wid >= total_ch) return;
+    int c = wid, pi = 0;
     for (; pi < a.n_proj; ++pi) {
-        const int n = a.B * a.proj[pi].ch;
-        if (rem < n) break;
-        rem -= n;
+        if (c < a.proj[pi].ch) break;
+        c -= a.proj[pi].ch;
     }
     const TimeProj& pr = a.proj[pi];
-    const int b = rem / pr.ch, c = rem - b * pr.ch;
-    const float* e = a.emb_ws + ((size_t)pr.emb * a.B + b) * a.D;
     const float* w = pr.weight + (size_t)c * a.D;
-    float s = 0.f;
-    for (int d = lane; d < a.D; d += 64) s = fmaf(w[d], e[d], s);
-    s = wave_sum(s);
-    if (lane == 0) pr.out[(size_t)b * pr.ch + c] = s + pr.bias[c];
+    float wreg[8];                                          // D <= 512
+#pragma unroll
+    for (int k = 0; k < 8; ++k) wreg[k] = (lane + 64 * k) < a.D ? w[lane + 64 * k] : 0.f;
+    const float bias = pr.bias[c];
+    for (int b = 0; b < a.B; ++b) {
+        const float* e = a.emb_ws + ((size_t)pr.emb * a.B + b) * a.D;
+        float s = 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (lane + 64 * k < a.D) s = fmaf(wreg[k], e[lane + 64 * k], s);
+        s = wave_sum(s);
+        if (lane == 0) pr.out[(size_t)b * pr.ch + c] = s + bias;
+    }
 }
 
 // ---- K19(final) + K22: 3x3, pad 1, C -> 1 output channel, then divide by sigma(t) ------------------------
 // reference score_unet.py:489 (final_layer.conv), :876-877 and marginal_prob_std :881-897.
-// HBM-bound: 16 lanes share one output pixel, each owns a float4 channel slice per tap (C = 64 -> one slice).
+// HBM/L2-bound.  16 lanes share a strip of 8 consecutive output pixels of one row; each lane owns a float4 channel
+// slice (C = 64 -> exactly one).  A loaded input column (3 rows x 1 pixel) feeds up to 3 outputs, so a strip needs
+// 30 float4 loads per lane instead of 72; the 16-lane partial sums are combined with wavefront shuffles.
 __global__ __launch_bounds__(256) void conv3x3_cout1_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                             const float* __restrict__ bias, const float* __restrict__ t,
                                                             float sigma, float* __restrict__ out, int B, int H, int W,
                                                             int C) {
+    constexpr int SW = 8;
     const int sub = threadIdx.x & 15;
-    const size_t npix = (size_t)B * H * W;
+    const int strips_per_row = (W + SW - 1) / SW;
+    const size_t nstrips = (size_t)B * H * strips_per_row;
     const size_t gstride = (size_t)gridDim.x * (blockDim.x >> 4);
-    for (size_t pix = (size_t)blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);; pix += gstride) {
-        // all 16 lanes of a group share `pix`; whole waves leave together only when every group is done
-        const bool live = pix < npix;
-        if (__all(!live)) break;
-        float acc = 0.f;
-        int b = 0;
+    for (size_t sidx = (size_t)blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4);; sidx += gstride) {
+        const bool live = sidx < nstrips;
+        if (__all(!live)) break;                     // whole waves leave together (shuffles below need all lanes)
+        float acc[SW];
+#pragma unroll
+        for (int o = 0; o < SW; ++o) acc[o] = 0.f;
+        int b = 0, oy = 0, ox0 = 0;
         if (live) {
-            const int ox = (int)(pix % W);
-            const int oy = (int)((pix / W) % H);
-            b = (int)(pix / ((size_t)W * H));
+            const int sr = (int)(sidx % strips_per_row);
+            const size_t row = sidx / strips_per_row;
+            oy = (int)(row % H);
+            b = (int)(row / H);
+            ox0 = sr * SW;
+            for (int c = sub * 4; c < C; c += 64) {
+                f32x4 wv[3][3];
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh) {
-                const int iy = oy + kh - 1;
-                if ((unsigned)iy >= (unsigned)H) continue;
+                for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw) {
-                    const int ix = ox + kw - 1;
-                    if ((unsigned)ix >= (unsigned)W) continue;
-                    const float* xp = x + (((size_t)b * H + iy) * W + ix) * C;
-                    const float* wp = w + (kh * 3 + kw) * C;
-                    for (int c = sub * 4; c < C; c += 64) {
-                        const f32x4 xv = *reinterpret_cast<const f32x4*>(xp + c);
-                        const f32x4 wv = *reinterpret_cast<const f32x4*>(wp + c);
-                        acc = fmaf(xv[0], wv[0], acc);
-                        acc = fmaf(xv[1], wv[1], acc);
-                        acc = fmaf(xv[2], wv[2], acc);
-                        acc = fmaf(xv[3], wv[3], acc);
+                    for (int kw = 0; kw < 3; ++kw) wv[kh][kw] = *reinterpret_cast<const f32x4*>(w + (kh * 3 + kw) * C + c);
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    const int iy = oy + kh - 1;
+                    if ((unsigned)iy >= (unsigned)H) continue;
+                    const float* rowp = x + (((size_t)b * H + iy) * W) * C + c;
+#pragma unroll
+                    for (int j = 0; j < SW + 2; ++j) {       // input column ox0 - 1 + j
+                        const int ix = ox0 - 1 + j;
+                        if ((unsigned)ix >= (unsigned)W) continue;
+                        const f32x4 xv = *reinterpret_cast<const f32x4*>(rowp + (size_t)ix * C);
+#pragma unroll
+                        for (int kw = 0; kw < 3; ++kw) {     // contributes to output o = j - kw
+                            const int o = j - kw;
+                            if (o < 0 || o >= SW) continue;
+                            const f32x4 ww = wv[kh][kw];
+                            acc[o] = fmaf(xv[0], ww[0], acc[o]);
+                            acc[o] = fmaf(xv[1], ww[1], acc[o]);
+                            acc[o] = fmaf(xv[2], ww[2], acc[o]);
+                            acc[o] = fmaf(xv[3], ww[3], acc[o]);
+                        }
                     }
                 }
             }
         }
 #pragma unroll
-        for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-        if (live && sub == 0) {
-            float v = acc + bias[0];
+        for (int o = 0; o < SW; ++o) {
+#pragma unroll
+            for (int sft = 8; sft > 0; sft >>= 1) acc[o] += __shfl_xor(acc[o], sft, 64);
+        }
+        if (live && sub < SW && ox0 + sub < W) {
+            float v = 0.f;
+#pragma unroll
+            for (int o = 0; o < SW; ++o) v = (sub == o) ? acc[o] : v;
+            v += bias[0];
             if (t != nullptr) {
                 const float ls = logf(sigma);
                 const float var = (expf((2.f * t[b]) * ls) - 1.f) / (2.f * ls);
                 v /= fmaxf(sqrtf(var), 1e-5f);
             }
-            out[pix] = v;
+            out[((size_t)b * H + oy) * W + ox0 + sub] = v;
         }
     }
 }
@@ -264,9 +294,10 @@ int sbgm_launch_time_embed(const TimeEmbedArgs& a, hipStream_t st) {
     const int total = a.n_emb * a.B * a.D;
     hipLaunchKernelGGL(time_embed_kernel, dim3((total + 255) / 256), dim3(256), 0, st, a);
     SBGM_LAUNCH_CHECK();
-    int total_out = 0;
-    for (int i = 0; i < a.n_proj; ++i) total_out += a.B * a.proj[i].ch;
-    hipLaunchKernelGGL(time_proj_kernel, dim3((total_out + 3) / 4), dim3(256), 0, st, a, total_out);
+    SBGM_CHECK(a.D <= 512, "time_embed: D=%d > 512 unsupported", a.D);
+    int total_ch = 0;
+    for (int i = 0; i < a.n_proj; ++i) total_ch += a.proj[i].ch;
+    hipLaunchKernelGGL(time_proj_kernel, dim3((total_ch + 3) / 4), dim3(256), 0, st, a, total_ch);
     SBGM_LAUNCH_CHECK();
     return 0;
 }
@@ -274,8 +305,8 @@ int sbgm_launch_time_embed(const TimeEmbedArgs& a, hipStream_t st) {
 int sbgm_launch_conv3x3_cout1(const float* x, const float* w_tap_c, const float* bias, const float* t, float sigma,
                               float* out, int B, int H, int W, int C, hipStream_t st) {
     SBGM_CHECK(C % 4 == 0, "conv3x3_cout1: C=%d must be a multiple of 4", C);
-    const size_t npix = (size_t)B * H * W;
-    hipLaunchKernelGGL(conv3x3_cout1_kernel, dim3((int)std::min<size_t>((npix + 15) / 16, 4096)), dim3(256), 0, st, x,
+    const size_t nstrips = (size_t)B * H * ((W + 7) / 8);
+    hipLaunchKernelGGL(conv3x3_cout1_kernel, dim3((int)std::min<size_t>((nstrips + 15) / 16, 8192)), dim3(256), 0, st, x,
                        w_tap_c, bias, t, sigma, out, B, H, W, C);
     SBGM_LAUNCH_CHECK();
     return 0;

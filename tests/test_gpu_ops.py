@@ -39,7 +39,8 @@ def pad_c(c):
     return 4 if c <= 4 else 8 if c <= 8 else (c + 15) // 16 * 16
 
 
-def run_conv(x, w, stride, pad, scale=None, bias=None, tbias=None, res=None, relu=False, after=False, tile=(0, 0), splits=0):
+def run_conv(x, w, stride, pad, scale=None, bias=None, tbias=None, res=None, relu=False, after=False, tile=(0, 0), splits=0, wpt=0,
+             gelu=False):
     B, Cin, H, W = x.shape
     Cout, _, KH, KW = w.shape
     cp = pad_c(Cin)
@@ -54,7 +55,8 @@ def run_conv(x, w, stride, pad, scale=None, bias=None, tbias=None, res=None, rel
     sc, bi, tb, rs = dv(scale), dv(bias), dv(tbias), dv(None if res is None else nhwc(res))
     ws = torch.empty(max(1, splits) * out.numel(), device=DEV)
     a = N.ConvArgs(xd.data_ptr(), packed.data_ptr(), out.data_ptr(), N.ptr(sc), N.ptr(bi), N.ptr(tb), N.ptr(rs), B, H, W, cp,
-                   Cout, KH, KW, stride, pad, int(relu), int(after), tile[0], tile[1], splits, ws.data_ptr(), ws.numel())
+                   Cout, KH, KW, stride, pad, N.GELU if gelu else (N.RELU if relu else N.NONE), int(after), tile[0], tile[1], splits, wpt,
+                   ws.data_ptr(), ws.numel())
     N.check(lib().sbgm_conv2d_fwd(C.byref(a), N.stream()))
     torch.cuda.synchronize()
     return nchw(out.cpu())
@@ -100,6 +102,25 @@ def test_conv_tiles(case, tile):
     x, w = rnd(B, Cin, H, W), rnd(Cout, Cin, K, K, seed=1, scale=1.0 / math.sqrt(Cin * K * K))
     got = run_conv(x, w, s, p, tile=tile)
     assert relerr(got, ref_conv(x, w, s, p)) < 2e-5
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("wpt", [2, 4])
+@pytest.mark.parametrize("tile", [(4, 4), (4, 1), (2, 2)])
+def test_conv_in_workgroup_splitk(case, wpt, tile):
+    B, Cin, H, W, Cout, K, s, p = case
+    x, w = rnd(B, Cin, H, W), rnd(Cout, Cin, K, K, seed=1, scale=1.0 / math.sqrt(Cin * K * K))
+    got = run_conv(x, w, s, p, tile=tile, wpt=wpt)
+    assert relerr(got, ref_conv(x, w, s, p)) < 2e-5
+
+
+def test_conv_gelu_epilogue_and_combined_splits():
+    B, Cin, H, W, Cout = 1, 256, 1, 40, 256
+    x, w, b = rnd(B, Cin, H, W), rnd(Cout, Cin, 1, 1, seed=2, scale=0.06), rnd(Cout, seed=4)
+    want = F.gelu(F.conv2d(x, w, b))
+    for kw in (dict(), dict(wpt=4), dict(wpt=2, splits=2), dict(splits=4)):
+        got = run_conv(x, w, 1, 0, bias=b, gelu=True, tile=(4, 2), **kw)
+        assert relerr(got, want) < 2e-5, kw
 
 
 @pytest.mark.parametrize("splits", [2, 3, 4, 9])
@@ -164,7 +185,7 @@ def test_groupnorm(C_, G, hw, full):
     skip, tb = (rnd(B, C_, H, W, seed=3), rnd(B, C_, seed=4)) if full else (None, None)
     xd = nhwc(x).to(DEV)
     y = torch.empty_like(xd)
-    ws = torch.empty(24 * B * G + 64, dtype=torch.uint8, device=DEV)
+    ws = torch.empty(1024 * B * G, dtype=torch.uint8, device=DEV)
     dv = lambda t: None if t is None else t.contiguous().to(DEV)  # noqa: E731
     g_, b_, s_, t_ = dv(gamma), dv(beta), dv(None if skip is None else nhwc(skip)), dv(tb)
     N.check(lib().sbgm_groupnorm_fwd(xd.data_ptr(), y.data_ptr(), N.ptr(g_), N.ptr(b_), N.ptr(s_), N.ptr(t_),
