@@ -214,6 +214,45 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         }
     }
 
+    // ---- fused tap projection (final decoder block): the 3x3, Cout=1 convolution that follows is linear, so each
+    // output pixel only needs the 9 per-tap dot products d[tap][m] = sum_co w[tap][co] * y[m][co] of THIS layer's
+    // output; y itself is never written.  The wave tile spans all output channels (checked on the host).
+    if (p.proj_w != nullptr) {
+        bool ok[FPX];
+        int mrow[FPX];
+#pragma unroll
+        for (int j = 0; j < FPX; ++j) {
+            const int m = m0 + 16 * j + r16;
+            ok[j] = m < p.M;
+            mrow[j] = ok[j] ? m : 0;
+            const int b = mrow[j] / ohw;
+#pragma unroll
+            for (int i = 0; i < FCO; ++i) acc[i][j] = conv_epilogue(acc[i][j], p, co0 + 16 * i + 4 * kq, (size_t)mrow[j], b);
+        }
+        const float* wl = p.proj_w + co0 + 4 * kq;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {          // fully unrolled: tap t+1's weights load under tap t's math
+            f32x4 w4[FCO];
+#pragma unroll
+            for (int i = 0; i < FCO; ++i) w4[i] = *reinterpret_cast<const f32x4*>(wl + tap * p.Cout + 16 * i);
+#pragma unroll
+            for (int j = 0; j < FPX; ++j) {
+                float s = 0.f;
+#pragma unroll
+                for (int i = 0; i < FCO; ++i) {
+                    s = fmaf(acc[i][j][0], w4[i][0], s);
+                    s = fmaf(acc[i][j][1], w4[i][1], s);
+                    s = fmaf(acc[i][j][2], w4[i][2], s);
+                    s = fmaf(acc[i][j][3], w4[i][3], s);
+                }
+                s += __shfl_xor(s, 16, 64);
+                s += __shfl_xor(s, 32, 64);
+                if (ok[j] && kq == (tap & 3)) p.proj_out[(size_t)tap * p.M + mrow[j]] = s;
+            }
+        }
+        return;
+    }
+
     // ---- epilogue: lane owns channels co0+16i+4kq..+3 of pixel m0+16j+r16 ------------------------------
     const bool partial = gridDim.y > 1;
     float* outp = p.out + (partial ? (size_t)blockIdx.y * (size_t)p.M * p.Cout : 0);
@@ -314,6 +353,8 @@ int sbgm_launch_conv(const ConvGeom& g, ConvParams p, const ConvTile& cfg, float
     SBGM_CHECK(p.Cs == 4 || p.Cs == 8 || p.Cs % 16 == 0, "conv: padded Cin %d unsupported", p.Cs);
     SBGM_CHECK(p.act == SBGM_ACT_NONE || p.act == SBGM_ACT_RELU || p.act == SBGM_ACT_GELU, "conv: act=%d does not fuse into the epilogue", p.act);
     SBGM_CHECK(cfg.ws == 1 || cfg.ws == 2 || cfg.ws == 4, "conv: waves-per-tile %d must be 1, 2 or 4", cfg.ws);
+    SBGM_CHECK(p.proj_w == nullptr || (p.Cout == 16 * cfg.fco && cfg.splits <= 1 && p.proj_out != nullptr),
+               "conv: the fused tap projection needs one wave tile over all %d output channels and no grid split-K", p.Cout);
     SBGM_CHECK((size_t)p.B * p.H * p.W * p.Cs * 4 < (1ull << 31), "conv: input tensor exceeds 2 GiB buffer window");
     p.OH = (p.H + 2 * g.pad - g.kh) / g.stride + 1;
     p.OW = (p.W + 2 * g.pad - g.kw) / g.stride + 1;

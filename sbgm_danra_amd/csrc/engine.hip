@@ -43,7 +43,7 @@ struct BlockW { ConvW c1, c2, ds; BNW bn1, bn2, dsbn; bool has_ds; int cin, cout
 struct DecW { ConvW up, conv; Param *n1g, *n1b, *n2g, *n2b, *freq, *tpw, *tpb; AttnW attn; bool has_attn; int cin, cout; };
 
 struct ConvOpKey {
-    int kh, kw, s, p, B, H, W, Cs, Cout;
+    int kh, kw, s, p, B, H, W, Cs, Cout, proj;
     bool operator<(const ConvOpKey& o) const { return std::memcmp(this, &o, sizeof(*this)) < 0; }
 };
 
@@ -311,9 +311,10 @@ int sbgm_model::fold_bn(hipStream_t st) {
 // small-spatial layers whose M*Cout is too small even with small tiles.
 ConvTile sbgm_model::pick_tile(const ConvGeom& g, const ConvParams& p) {
     const int OH = (p.H + 2 * g.pad - g.kh) / g.stride + 1, OW = (p.W + 2 * g.pad - g.kw) / g.stride + 1;
-    ConvOpKey key{g.kh, g.kw, g.stride, g.pad, p.B, p.H, p.W, p.Cs, p.Cout};
+    ConvOpKey key{g.kh, g.kw, g.stride, g.pad, p.B, p.H, p.W, p.Cs, p.Cout, p.proj_w != nullptr};
     auto it = tuned.find(key);
     if (it != tuned.end()) return it->second;
+    if (p.proj_w) return ConvTile{p.Cout / 16, 2, 1, 1};
     const int M = p.B * OH * OW;
     const int nsteps = sbgm_conv_nsteps(g.kh, g.kw, p.Cs);
     const int target = 2048;                 // ~2 waves per SIMD
@@ -337,18 +338,19 @@ int sbgm_model::conv(const ConvGeom& g, ConvParams p, hipStream_t st) {
     const size_t mc = (size_t)p.B * OH * OW * p.Cout;
     if (tuning) {
         // time every candidate on this op, keep the fastest
-        ConvOpKey key{g.kh, g.kw, g.stride, g.pad, p.B, p.H, p.W, p.Cs, p.Cout};
+        ConvOpKey key{g.kh, g.kw, g.stride, g.pad, p.B, p.H, p.W, p.Cs, p.Cout, p.proj_w != nullptr};
         if (tuned.find(key) == tuned.end()) {
             const int nsteps = sbgm_conv_nsteps(g.kh, g.kw, p.Cs);
             std::vector<ConvTile> cands;
             const int tiles[6][2] = {{4, 4}, {4, 2}, {4, 1}, {2, 4}, {2, 2}, {2, 1}};
             for (auto& t : tiles) {
                 if (p.Cout % (16 * t[0])) continue;
+                if (p.proj_w && 16 * t[0] != p.Cout) continue;
                 const long ntile = (long)(((size_t)p.B * OH * OW + 16 * t[1] - 1) / (16 * t[1])) * (p.Cout / (16 * t[0]));
                 for (int ws : {1, 2, 4}) {
                     if (ws > 1 && (nsteps / ws < 2 || ntile * ws > 32768)) continue;
                     for (int sp : {1, 2, 4, 8, 16}) {
-                        if (sp > 1 && (nsteps / (sp * ws) < 2 || ntile * ws >= 4096)) continue;   // already enough waves
+                        if (sp > 1 && (p.proj_w || nsteps / (sp * ws) < 2 || ntile * ws >= 4096)) continue;   // already enough waves
                         cands.push_back(ConvTile{t[0], t[1], sp, ws});
                     }
                 }
@@ -571,12 +573,23 @@ int sbgm_model::forward(const float* x, const float* t, const int64_t* y, const 
         float* up = wsalloc((size_t)B * H * W * ci);
         if (!up) return 1;
         if (sbgm_launch_upsample2x(cur, up, B, ch, cw_, ci, st)) return 1;
-        float* a = wsalloc((size_t)B * H * W * ci);
-        if (!a) return 1;
         ConvParams p{};
-        p.x = up; p.wp = fin_up.w->dev; p.out = a; p.bias = fin_up.b->dev; p.B = B; p.H = H; p.W = W; p.Cs = ci; p.Cout = ci;
-        if (conv(ConvGeom{3, 3, 1, 1}, p, st)) return 1;
-        if (sbgm_launch_conv3x3_cout1(a, fin_conv.w->dev, fin_conv.b->dev, t, cfg.sigma, out, B, H, W, ci, st)) return 1;
+        p.x = up; p.wp = fin_up.w->dev; p.bias = fin_up.b->dev; p.B = B; p.H = H; p.W = W; p.Cs = ci; p.Cout = ci;
+        if (ci == 64) {
+            // conv_up's 64-channel output feeds only the linear 3x3 Cout=1 conv: project onto its 9 taps in the epilogue
+            // (9 floats per pixel instead of 64) and finish with a 9-point gather.
+            float* d = wsalloc((size_t)9 * B * H * W);
+            if (!d) return 1;
+            p.out = d; p.proj_w = fin_conv.w->dev; p.proj_out = d;
+            if (conv(ConvGeom{3, 3, 1, 1}, p, st)) return 1;
+            if (sbgm_launch_tap_stencil(d, fin_conv.b->dev, t, cfg.sigma, out, B, H, W, st)) return 1;
+        } else {
+            float* a = wsalloc((size_t)B * H * W * ci);
+            if (!a) return 1;
+            p.out = a;
+            if (conv(ConvGeom{3, 3, 1, 1}, p, st)) return 1;
+            if (sbgm_launch_conv3x3_cout1(a, fin_conv.w->dev, fin_conv.b->dev, t, cfg.sigma, out, B, H, W, ci, st)) return 1;
+        }
     }
     return 0;
 }

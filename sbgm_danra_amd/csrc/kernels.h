@@ -23,6 +23,8 @@ struct ConvParams {
     const float* res;     // [M][Cout] or null (residual / skip)
     int B, H, W, Cs, Cout;
     int act, tbias_after_act;
+    const float* proj_w;  // [9][Cout] or null: fuse the following 3x3 Cout=1 conv's per-tap channel dot products
+    float* proj_out;      // [9][M] planar tap sums (then `out` is not written)
     // filled by sbgm_launch_conv:
     int OH, OW, M, cb_per_tap, nsteps, steps_per_split, n_px_tiles, n_co_tiles;
     uint32_t x_bytes, w_bytes;
@@ -69,6 +71,9 @@ int sbgm_launch_time_embed(const TimeEmbedArgs& a, hipStream_t st);
 // final 3x3 conv with a single output channel, fused with the division by sigma(t): out NCHW [B,1,H,W]
 int sbgm_launch_conv3x3_cout1(const float* x, const float* w_tap_c, const float* bias, const float* t, float sigma,
                               float* out, int B, int H, int W, int C, hipStream_t st);
+// out[b,y,x] = (bias + sum_taps d[tap][b, y+kh-1, x+kw-1]) / sigma(t_b): finishes the fused final conv
+int sbgm_launch_tap_stencil(const float* d, const float* bias, const float* t, float sigma, float* out, int B, int H, int W,
+                            hipStream_t st);
 int sbgm_launch_pack_cout1_weight(const float* w_oihw, float* w_tap_c, int C, hipStream_t st);
 
 // ---- norm.hip ------------------------------------------------------------------------------------------

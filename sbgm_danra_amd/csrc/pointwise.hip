@@ -124,31 +124,41 @@ __global__ __launch_bounds__(256) void time_embed_kernel(TimeEmbedArgs a) {
 }
 
 // ---- K2: all time projections of one forward in one launch ---------------------------------------------------------
-// One wave per (projection, output channel): the weight row stays in registers and is dotted with every sample's
-// embedding (the embeddings are tiny and L2-resident), so the 1.5 MB of projection weights are read once per launch.
-__global__ __launch_bounds__(256) void time_proj_kernel(TimeEmbedArgs a, int total_ch) {
+// One wave per (projection, output channel, group of 8 samples): the weight row sits in registers, the 8 dot
+// products are accumulated with independent loads and reduced with interleaved wavefront butterflies.
+constexpr int TP_BG = 8;
+__global__ __launch_bounds__(256) void time_proj_kernel(TimeEmbedArgs a, int total_ch, int bgroups) {
     const int lane = threadIdx.x & 63;
     const int wid = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (wid >= total_ch) return;
-    int c = wid, pi = 0;
+    if (wid >= total_ch * bgroups) return;
+    const int bg = wid % bgroups;
+    int c = wid / bgroups, pi = 0;
     for (; pi < a.n_proj; ++pi) {
         if (c < a.proj[pi].ch) break;
         c -= a.proj[pi].ch;
     }
     const TimeProj& pr = a.proj[pi];
     const float* w = pr.weight + (size_t)c * a.D;
-    float wreg[8];                                          // D <= 512
+    float acc[TP_BG];
 #pragma unroll
-    for (int k = 0; k < 8; ++k) wreg[k] = (lane + 64 * k) < a.D ? w[lane + 64 * k] : 0.f;
-    const float bias = pr.bias[c];
-    for (int b = 0; b < a.B; ++b) {
-        const float* e = a.emb_ws + ((size_t)pr.emb * a.B + b) * a.D;
-        float s = 0.f;
+    for (int j = 0; j < TP_BG; ++j) acc[j] = 0.f;
+    for (int d = lane; d < a.D; d += 64) {
+        const float wv = w[d];
 #pragma unroll
-        for (int k = 0; k < 8; ++k)
-            if (lane + 64 * k < a.D) s = fmaf(wreg[k], e[lane + 64 * k], s);
-        s = wave_sum(s);
-        if (lane == 0) pr.out[(size_t)b * pr.ch + c] = s + bias;
+        for (int j = 0; j < TP_BG; ++j) {
+            const int b = min(bg * TP_BG + j, a.B - 1);
+            acc[j] = fmaf(wv, a.emb_ws[((size_t)pr.emb * a.B + b) * a.D + d], acc[j]);
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+        for (int j = 0; j < TP_BG; ++j) acc[j] += __shfl_xor(acc[j], o, 64);
+    if (lane < TP_BG && bg * TP_BG + lane < a.B) {
+        float v = 0.f;
+#pragma unroll
+        for (int j = 0; j < TP_BG; ++j) v = (lane == j) ? acc[j] : v;
+        pr.out[(size_t)(bg * TP_BG + lane) * pr.ch + c] = v + pr.bias[c];
     }
 }
 
@@ -229,6 +239,37 @@ __global__ __launch_bounds__(256) void conv3x3_cout1_kernel(const float* __restr
     }
 }
 
+// Finish of the fused final block: 9-point gather over the planar per-tap sums written by the conv_up epilogue.
+__global__ __launch_bounds__(256) void tap_stencil_kernel(const float* __restrict__ d, const float* __restrict__ bias,
+                                                          const float* __restrict__ t, float sigma, float* __restrict__ out,
+                                                          int B, int H, int W) {
+    const size_t M = (size_t)B * H * W;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (size_t)gridDim.x * blockDim.x) {
+        const int x = (int)(i % W);
+        const int y = (int)((i / W) % H);
+        const int b = (int)(i / ((size_t)W * H));
+        float v = 0.f;
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int iy = y + kh - 1;
+            if ((unsigned)iy >= (unsigned)H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ix = x + kw - 1;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                v += d[(size_t)(kh * 3 + kw) * M + ((size_t)b * H + iy) * W + ix];
+            }
+        }
+        v += bias[0];
+        if (t != nullptr) {
+            const float ls = logf(sigma);
+            const float var = (expf((2.f * t[b]) * ls) - 1.f) / (2.f * ls);
+            v /= fmaxf(sqrtf(var), 1e-5f);
+        }
+        out[i] = v;
+    }
+}
+
 __global__ void pack_cout1_weight_kernel(const float* w, float* wp, int C) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;   // wp[tap][c] = w[0][c][kh][kw]
     if (i < 9 * C) {
@@ -294,10 +335,10 @@ int sbgm_launch_time_embed(const TimeEmbedArgs& a, hipStream_t st) {
     const int total = a.n_emb * a.B * a.D;
     hipLaunchKernelGGL(time_embed_kernel, dim3((total + 255) / 256), dim3(256), 0, st, a);
     SBGM_LAUNCH_CHECK();
-    SBGM_CHECK(a.D <= 512, "time_embed: D=%d > 512 unsupported", a.D);
     int total_ch = 0;
     for (int i = 0; i < a.n_proj; ++i) total_ch += a.proj[i].ch;
-    hipLaunchKernelGGL(time_proj_kernel, dim3((total_ch + 3) / 4), dim3(256), 0, st, a, total_ch);
+    const int bgroups = (a.B + TP_BG - 1) / TP_BG;
+    hipLaunchKernelGGL(time_proj_kernel, dim3((total_ch * bgroups + 3) / 4), dim3(256), 0, st, a, total_ch, bgroups);
     SBGM_LAUNCH_CHECK();
     return 0;
 }
@@ -308,6 +349,13 @@ int sbgm_launch_conv3x3_cout1(const float* x, const float* w_tap_c, const float*
     const size_t nstrips = (size_t)B * H * ((W + 7) / 8);
     hipLaunchKernelGGL(conv3x3_cout1_kernel, dim3((int)std::min<size_t>((nstrips + 15) / 16, 8192)), dim3(256), 0, st, x,
                        w_tap_c, bias, t, sigma, out, B, H, W, C);
+    SBGM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sbgm_launch_tap_stencil(const float* d, const float* bias, const float* t, float sigma, float* out, int B, int H, int W,
+                            hipStream_t st) {
+    hipLaunchKernelGGL(tap_stencil_kernel, dim3(stream_blocks((size_t)B * H * W)), dim3(256), 0, st, d, bias, t, sigma, out, B, H, W);
     SBGM_LAUNCH_CHECK();
     return 0;
 }
