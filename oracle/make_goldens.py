@@ -23,9 +23,9 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 REF = "/root/reference"
+sys.path.insert(0, ROOT)                                   # for `oracle`
 sys.path.insert(0, os.path.join(HERE, "_tv_standin"))
-sys.path.insert(0, REF)
-sys.path.insert(0, ROOT)
+sys.path.insert(0, REF)                                    # FIRST: `sbgm` must resolve to the reference, not the repo's alias
 
 import torch.nn as nn                                                   # noqa: E402
 import sbgm.score_unet as R                                             # noqa: E402  (the reference)

@@ -1,0 +1,38 @@
+"""`generation_main(cfg)` — reference sbgm/evaluate_sbgm/generation_main.py:47-181: seed, model, checkpoint
+(`network_params`), generation loader, `SampleGenerator`, then every `cfg.evaluation.gen_type`."""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+from .. import parallel
+from ..training_utils import get_gen_dataloader, get_model, setup_logger
+from ..utils import get_model_string
+from .generation import SampleGenerator
+
+
+def generation_main(cfg, dataloader=None):
+    seed = cfg["evaluation"]["seed"]
+    torch.manual_seed(seed)
+    torch.cuda.manual_seed(seed)
+    np.random.seed(seed)
+    gen_dir = os.path.join(cfg["paths"]["sample_dir"], "generation", get_model_string(cfg))
+    log = setup_logger(os.path.join(gen_dir, "logs"), name="gen_log")
+    rank, world, local = parallel.init_distributed()
+    dev = cfg["training"]["device"]
+    device = torch.device("cuda", local) if dev == "cuda" and torch.cuda.is_available() else torch.device("cpu")
+    model, ckpt_dir, ckpt_name = get_model(cfg)
+    model = model.to(device)
+    state = torch.load(os.path.join(ckpt_dir, ckpt_name), map_location=device, weights_only=True)["network_params"]
+    model.load_state_dict(state)
+    log.info(f"[INFO] Model checkpoint loaded from: {ckpt_dir}/{ckpt_name}")
+    gen = SampleGenerator(cfg, model, dataloader if dataloader is not None else get_gen_dataloader(cfg), None, device)
+    out = {}
+    for kind in cfg["evaluation"]["gen_type"]:
+        if kind not in ("multiple", "single", "repeated"):
+            raise ValueError(f"\nUnknown generation type: {kind}\n")
+        log.info(f"[INFO] Running generation type: {kind}")
+        out[kind] = getattr(gen, f"generate_{kind}")()
+    return out

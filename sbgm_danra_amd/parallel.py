@@ -1,0 +1,106 @@
+"""One process per GPU (torch.distributed; backend "nccl" = RCCL over xGMI on ROCm, "gloo" on CPU for tests).
+
+The reference is single-device; this is the data-parallel layer around its two loops:
+
+* sampling — whole independent batches per rank, NO data-path collective (the Langevin corrector's batch-mean
+  gradient norm, reference score_sampling.py:201, stays inside one rank's batch, so every rank is bit-comparable
+  with a single-GPU run of the same batch); results are gathered only on request.
+* training — batch-sharded data parallel with exactly one exchange step: a sum all-reduce of one flattened fp32
+  gradient bucket (76.3 MB for the default model) between `backward()` and `optimizer.step()`
+  (reference training.py:405 -> :407), divided by the world size.  BatchNorm keeps per-replica statistics
+  (PyTorch-DDP default).
+"""
+from __future__ import annotations
+
+import os
+from typing import Iterable, List
+
+import torch
+import torch.distributed as dist
+
+
+def init_distributed(backend: str | None = None) -> tuple[int, int, int]:
+    """Join the process group described by RANK/WORLD_SIZE/LOCAL_RANK/MASTER_* (torchrun contract).
+    Returns (rank, world, local_rank); world == 1 without those variables (no group is created)."""
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    rank, local = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+            dist.init_process_group(backend, device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
+    return rank, world, local
+
+
+def world() -> tuple[int, int]:
+    return (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
+
+
+def shard_range(n_items: int, rank: int, world_size: int) -> range:
+    """Contiguous, balanced split of n_items independent units (batches / tiles): first n%world ranks get one more."""
+    q, r = divmod(n_items, world_size)
+    start = rank * q + min(rank, r)
+    return range(start, start + q + (1 if rank < r else 0))
+
+
+class GradientBucket:
+    """Flattened fp32 gradient bucket + one sum all-reduce, averaged over ranks."""
+
+    def __init__(self, params: Iterable[torch.nn.Parameter]):
+        self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
+        if not self.params:
+            raise ValueError("GradientBucket needs at least one trainable parameter")
+        dev = self.params[0].device
+        self.numel = sum(p.numel() for p in self.params)
+        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+
+    def all_reduce_(self) -> None:
+        rank, ws = world()
+        if ws == 1:
+            return
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            if p.grad is None:
+                self.flat[off:off + n].zero_()
+            else:
+                self.flat[off:off + n].copy_(p.grad.reshape(-1))
+            off += n
+        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+        self.flat.div_(ws)
+        off = 0
+        for p in self.params:
+            n = p.numel()
+            if p.grad is None:
+                p.grad = torch.empty_like(p)
+            p.grad.copy_(self.flat[off:off + n].view_as(p))
+            off += n
+
+
+def broadcast_parameters(module: torch.nn.Module, src: int = 0) -> None:
+    """Make every replica start from rank `src`'s weights and buffers."""
+    if world()[1] == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src)
+
+
+def sample_sharded(sampler, n_batches: int, make_kwargs, gather: bool = False):
+    """Run `sampler(**make_kwargs(i))` for this rank's share of `n_batches` independent batches.
+    Returns {batch index: sample tensor}; with gather=True rank 0 receives every rank's results (CPU tensors)."""
+    rank, ws = world()
+    mine = {i: sampler(**make_kwargs(i)) for i in shard_range(n_batches, rank, ws)}
+    if not gather or ws == 1:
+        return mine
+    payload = {i: v.detach().cpu() for i, v in mine.items()}
+    out = [None] * ws if rank == 0 else None
+    dist.gather_object(payload, out, dst=0)
+    if rank != 0:
+        return mine
+    merged = {}
+    for d in out:
+        merged.update(d)
+    return merged

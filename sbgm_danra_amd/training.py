@@ -1,0 +1,146 @@
+"""`TrainingPipeline_general` — the reference's training hot loop and its two satellites (reference sbgm/training.py:
+__init__ :41-117, xavier_init_weights :188-201, load_checkpoint :203-222, save_model :224-244, train_batches :246-422,
+train :424-508, validate_batches :510-609, generate_and_plot_samples :611-786).
+
+Same constructor signature, same per-batch order (zero_grad -> loss_fn -> backward -> step -> .item()), same checkpoint
+dict (`network_params`, `optimizer_params`), best-validation checkpointing, per-epoch pickled losses.  Kept out:
+matplotlib plotting (`generate_and_plot_samples` only generates and returns the samples) and the precipitation
+back-transform of the sentinel.  New relative to the reference: when a process group exists
+the gradients are all-reduced (one flattened bucket, RCCL) between backward and step.
+"""
+from __future__ import annotations
+
+import logging
+import os
+import pickle
+
+import torch
+import torch.nn as nn
+
+from . import parallel
+from .score_sampling import Euler_Maruyama_sampler, ode_sampler, pc_sampler
+from .utils import extract_samples, get_model_string, report_precip_extremes
+
+logger = logging.getLogger(__name__)
+_SAMPLERS = {"pc_sampler": pc_sampler, "Euler_Maruyama_sampler": Euler_Maruyama_sampler, "ode_sampler": ode_sampler}
+
+
+class TrainingPipeline_general:
+    def __init__(self, model, loss_fn, marginal_prob_std_fn, diffusion_coeff_fn, optimizer, device, lr_scheduler, cfg):
+        self.model, self.loss_fn, self.optimizer, self.lr_scheduler, self.cfg = model, loss_fn, optimizer, lr_scheduler, cfg
+        self.marginal_prob_std_fn, self.diffusion_coeff_fn = marginal_prob_std_fn, diffusion_coeff_fn
+        self.model.debug_pre_sigma_div = cfg["training"].get("debug_pre_sigma_div", True)
+        self.device = device if device is not None else ("cuda" if torch.cuda.is_available() else "cpu")
+        t = cfg["training"]
+        self.weight_init, self.custom_weight_initializer = t["weight_init"], t.get("custom_weight_initializer")
+        self.sdf_weighted_loss, self.with_ema = t.get("sdf_weighted_loss", False), t.get("with_ema", False)
+        if self.weight_init:
+            self.model.apply(self.custom_weight_initializer or self.xavier_init_weights)
+        mon = (cfg.get("monitoring", {}) or {}).get("extreme_prcp", {}) or {}
+        self.extreme_enabled = bool(mon.get("enabled", False))
+        self.extreme_every_step = int(mon.get("every_steps", 50))
+        self.extreme_threshold_mm = float(mon.get("threshold_mm", 500.0))
+        self.model_string = get_model_string(cfg)
+        self.checkpoint_dir = cfg["paths"]["checkpoint_dir"]
+        self.checkpoint_name = self.model_string + ".pth.tar"
+        self.checkpoint_path = os.path.join(self.checkpoint_dir, self.checkpoint_name)
+        self.path_losses = os.path.join(cfg["paths"]["path_save"], "samples", self.model_string, "losses")
+        for d in (self.checkpoint_dir, self.path_losses):
+            os.makedirs(d, exist_ok=True)
+        self._bucket = None
+
+    @staticmethod
+    def xavier_init_weights(m):
+        if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+            nn.init.xavier_uniform_(m.weight)
+            if m.bias is not None and torch.is_tensor(m.bias):
+                m.bias.data.fill_(0.01)
+
+    def load_checkpoint(self, checkpoint_path, load_ema=False, device=None):
+        state = torch.load(checkpoint_path, map_location=device or self.device, weights_only=True)["network_params"]
+        self.model.load_state_dict(state)
+
+    def save_model(self, dirname="./model_params", filename="SBGM.pth"):
+        os.makedirs(dirname, exist_ok=True)
+        return torch.save({"network_params": self.model.state_dict(), "optimizer_params": self.optimizer.state_dict()},
+                          os.path.join(dirname, filename))
+
+    def _loss(self, samples):
+        x, seasons, cond, _lsm_hr, lsm, sdf, topo, _hp, _lp = extract_samples(samples, self.device)
+        return x, self.loss_fn(self.model, x, self.marginal_prob_std_fn, y=seasons, cond_img=cond, lsm_cond=lsm,
+                               topo_cond=topo, sdf_cond=sdf if self.sdf_weighted_loss else None)
+
+    def train_batches(self, dataloader, epochs=10, current_epoch=1, verbose=True, use_mixed_precision=False):
+        if use_mixed_precision:
+            raise NotImplementedError("fp32 only: the reference's autocast branch is commented out (training.py:325-343)")
+        self.model.train()
+        if self._bucket is None and parallel.world()[1] > 1:
+            self._bucket = parallel.GradientBucket(self.model.parameters())
+        loss_sum = 0.0
+        for idx, samples in enumerate(dataloader):
+            self.optimizer.zero_grad()
+            x, batch_loss = self._loss(samples)
+            if self.extreme_enabled and idx % self.extreme_every_step == 0:
+                report_precip_extremes(x.detach().cpu(), "ground_truth_hr", self.extreme_threshold_mm, logger=logger.warning)
+            batch_loss.backward()
+            if self._bucket is not None:
+                self._bucket.all_reduce_()            # the one collective of the path
+            self.optimizer.step()
+            loss_sum += batch_loss.item()
+        avg = loss_sum / max(1, len(dataloader))
+        if verbose:
+            logger.info(f"→ Epoch {current_epoch}/{epochs} completed: Avg. training Loss: {avg:.4f}")
+        return avg
+
+    def validate_batches(self, dataloader, verbose=True):
+        self.model.eval()
+        loss_sum = 0.0
+        with torch.inference_mode():
+            for samples in dataloader:
+                loss_sum += self._loss(samples)[1].item()
+        avg = loss_sum / max(1, len(dataloader))
+        if verbose:
+            logger.info(f"→ Validation Loss: {avg:.4f}")
+        return avg
+
+    def train(self, train_dataloader, val_dataloader, gen_dataloader, cfg, epochs=1, verbose=True, use_mixed_precision=False):
+        train_losses, val_losses = [], []
+        train_loss = val_loss = best = float("inf")
+        for epoch in range(1, epochs + 1):
+            self.epoch = epoch
+            train_loss = self.train_batches(train_dataloader, epochs, epoch, verbose, use_mixed_precision)
+            val_loss = self.validate_batches(val_dataloader, verbose)
+            train_losses.append(train_loss)
+            val_losses.append(val_loss)
+            if val_loss < best and parallel.world()[0] == 0:
+                best = val_loss
+                self.save_model(self.checkpoint_dir, self.checkpoint_name)
+                logger.info(f"→ Best model saved with validation loss: {best:.4f} at epoch {epoch}.")
+            with open(os.path.join(self.path_losses, f"losses_{self.model_string}.pkl"), "wb") as f:
+                pickle.dump({"train_losses": train_losses, "val_losses": val_losses}, f)
+            if cfg["visualization"].get("create_figs") and cfg["data_handling"].get("n_gen_samples", 0) > 0 and gen_dataloader is not None:
+                self.generate_and_plot_samples(gen_dataloader, cfg=cfg, epoch=epoch)
+        return train_loss, val_loss
+
+    def generate_and_plot_samples(self, gen_dataloader, cfg, epoch, **_):
+        """Per-epoch preview: first generation batch through cfg.sampler.sampler_type with the reference's kwargs
+        (training.py:683-695).  Returns the generated tensor [B,1,H,W] (plotting is out of scope)."""
+        if os.path.exists(self.checkpoint_path):
+            self.load_checkpoint(self.checkpoint_path)
+        self.model.eval()
+        sampler = _SAMPLERS.get(cfg["sampler"]["sampler_type"])
+        if sampler is None:
+            raise ValueError(f"Sampler type {cfg['sampler']['sampler_type']} not recognized.")
+        samples = next(iter(gen_dataloader))
+        x, seasons, cond, _lsm_hr, lsm, _sdf, topo, _hp, _lp = extract_samples(samples, self.device)
+        kw = dict(score_model=self.model, marginal_prob_std=self.marginal_prob_std_fn, diffusion_coeff=self.diffusion_coeff_fn,
+                  batch_size=x.shape[0], num_steps=cfg["sampler"]["n_timesteps"], device=self.device,
+                  img_size=cfg["highres"]["data_size"][0])
+        if sampler is not ode_sampler:
+            kw.update(y=seasons, cond_img=cond, lsm_cond=lsm, topo_cond=topo)
+        gen = sampler(**kw)
+        mon = (cfg.get("monitoring", {}) or {}).get("extreme_prcp", {}) or {}
+        if mon.get("enabled"):
+            report_precip_extremes(gen.detach().cpu(), f"generated_epoch_{epoch}", float(mon.get("threshold_mm", 500.0)),
+                                   logger=logger.warning)
+        return gen

@@ -1,0 +1,63 @@
+"""The four `sbgm/utils.py` helpers that touch the hot path: `extract_samples` (reference
+utils.py:405-480), `get_model_string` (:88-128), `load_config` (:1626-1640), `report_precip_extremes` (:1642-1671).
+Plotting, zarr/netCDF converters and the rest of that file are out of scope."""
+from __future__ import annotations
+
+import torch
+
+from .config_loader import Config, load_config, to_config  # noqa: F401
+
+
+def extract_samples(samples: dict, device=None):
+    """Batch dict -> (hr, classifier, lr(cat over sorted *_lr keys), lsm_hr, lsm, sdf, topo, hr_point, lr_point), on
+    `device`, images as fp32 — the tuple layout every reference caller unpacks."""
+    if device is None:
+        device = torch.device("cuda" if torch.cuda.is_available() else "cpu")
+
+    def img(k):
+        v = samples.get(k)
+        return None if v is None else v.to(device, non_blocking=True).float()
+
+    hr_keys = [k for k in samples if k.endswith("_hr") and not k.endswith("_original") and k != "lsm_hr"]
+    if not hr_keys:
+        raise ValueError("No HR image found in samples dictionary.")
+    hr = img(hr_keys[0])
+    cls = samples.get("classifier")
+    if cls is not None:
+        cls = cls.to(device, non_blocking=True)
+    lr_keys = sorted(k for k in samples if k.endswith("_lr") and not k.endswith("_original"))
+    lr = None if not lr_keys else (img(lr_keys[0]) if len(lr_keys) == 1 else torch.cat([img(k) for k in lr_keys], dim=1))
+    pts = [None if samples.get(k) is None else samples[k].to(device).float() for k in ("hr_point", "lr_point")]
+    return hr, cls, lr, img("lsm_hr"), img("lsm"), img("sdf"), img("topo"), pts[0], pts[1]
+
+
+def get_model_string(cfg) -> str:
+    """Checkpoint / output naming scheme of the reference (utils.py:88-128)."""
+    hr = tuple(cfg["highres"]["data_size"]) if cfg["highres"].get("data_size") is not None else (128, 128)
+    rf = cfg["lowres"].get("resize_factor", 1) or 1
+    if rf > 1:
+        hr = (hr[0] // rf, hr[1] // rf)
+    lr_vars = "_".join(cfg["lowres"]["condition_variables"] or [])
+    return (f"{cfg['experiment']['config_name']}__HR_{cfg['highres']['variable']}_{cfg['highres']['model']}__"
+            f"SIZE_{hr[0]}x{hr[1]}__LR_{lr_vars}_{cfg['lowres']['model']}__LOSS_{cfg['training']['loss_type']}__"
+            f"HEADS_{cfg['sampler']['num_heads']}__TIMESTEPS_{cfg['sampler']['n_timesteps']}")
+
+
+def report_precip_extremes(x_bt: torch.Tensor, name: str, cap_mm_day: float = 500.0, logger=print) -> dict:
+    """Per-sample sentinel on back-transformed precipitation: max above max(5 x p99.9, cap) or max below 0."""
+    flat = x_bt.flatten(1).float()
+    p999 = torch.quantile(flat, 0.999, dim=1).tolist()
+    mx = flat.max(dim=1).values.tolist()
+    ex = [m for p, m in zip(p999, mx) if m > max(5.0 * p, cap_mm_day)]
+    neg = [m for m in mx if m < 0]
+    for i, (p, m) in enumerate(zip(p999, mx)):
+        if m > max(5.0 * p, cap_mm_day):
+            logger(f"{name} sample {i} has extreme precipitation: max={m:.1f} mm/day > max(5xp99.9={p:.1f} mm/day)")
+        if m < 0:
+            logger(f"{name} sample {i} has negative precipitation: max={m:.1f} mm/day < 0")
+    out = {"has_extreme": bool(ex)}
+    if ex:
+        out.update(n_extreme=len(ex), extreme_values=ex)
+    if neg:
+        out.update(has_below_zero=True, n_below_zero=len(neg), below_zero_values=neg)
+    return out
