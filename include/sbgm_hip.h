@@ -149,6 +149,8 @@ typedef struct sbgm_conv_args {
     int tile_co, tile_px;    /* wave tile in 16-element fragments: {2,4} x {1,2,4}; 0 = default */
     int splits;              /* split-K over the grid (needs ws); 0/1 = off */
     int waves_per_tile;      /* in-workgroup split-K: 1, 2 or 4 waves share one tile; 0 = 1 */
+    int in_dil;              /* 0/1, or 2: read x through a zero-inserted grid (data gradient of a stride-2 conv) */
+    int out_h, out_w;        /* explicit output size (required with in_dil = 2), else 0 */
     float* ws;
     int64_t ws_floats;
 } sbgm_conv_args;
@@ -159,7 +161,8 @@ int sbgm_upsample2x_fwd(const float* x, float* y, int B, int H, int W, int C, vo
 /* nn.GroupNorm / nn.InstanceNorm2d (+ skip add, + time bias, + activation).  score_unet.py:480-483, :585-615.
  * gamma/beta NULL = no affine (InstanceNorm2d default).  stats_ws: >= 1024*B*G bytes. */
 int sbgm_groupnorm_fwd(const float* x, float* y, const float* gamma, const float* beta, const float* skip,
-                       const float* tbias, int act, int B, int HW, int C, int G, float eps, void* stats_ws, void* stream);
+                       const float* tbias, int act, int B, int HW, int C, int G, float eps, void* stats_ws,
+                       float* mean_rstd_out /* [B,G,2] or NULL */, void* stream);
 /* nn.LayerNorm(C).  score_unet.py:128-129 */
 int sbgm_layernorm_fwd(const float* x, float* y, const float* gamma, const float* beta, int M, int C, float eps, void* stream);
 /* nn.BatchNorm2d in training mode (+ residual, ReLU, time bias).  stats_ws: >= 24*C bytes. */
@@ -170,7 +173,8 @@ int sbgm_batchnorm_train_fwd(const float* x, float* y, const float* gamma, const
 int sbgm_mha_core_fwd(const float* qkv, float* out, int B, int S, int C, int heads, void* stream);
 /* SinusoidalEmbedding (+ label embedding) -> SiLU -> Linear, for one projection.  score_unet.py:41-45, :377-381 */
 int sbgm_time_proj_fwd(const float* t, const int64_t* y, const float* label_emb, const float* freqs, const float* weight,
-                       const float* bias, float* out, float* emb_ws, int B, int D, int ch, void* stream);
+                       const float* bias, float* out, float* emb_ws /* [B,D] silu(emb) */, float* emb_raw /* [B,D] or NULL */,
+                       int B, int D, int ch, void* stream);
 /* final_layer.conv (3x3, C->1) + division by marginal_prob_std(t).  score_unet.py:489, :876-877.
  * w_tap_c from sbgm_cout1_pack_weight; t NULL = no division. */
 int sbgm_cout1_pack_weight(const float* w_oihw, float* w_tap_c, int C, void* stream);
@@ -178,6 +182,36 @@ int sbgm_conv3x3_cout1_fwd(const float* x, const float* w_tap_c, const float* bi
                            int B, int H, int W, int C, void* stream);
 /* Elementwise activation in place (GELU between the attention FF linears, score_unet.py:132). */
 int sbgm_act_inplace(float* x, int64_t n, int act, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Training path: what `loss.backward()` (reference training.py:403-405) needs from each op above.
+ * Data gradients of convolutions / linears run sbgm_conv2d_fwd on weights packed by sbgm_conv_pack_weight_dgrad
+ * (stride-2 layers with in_dil = 2 and an explicit output size).
+ * ---------------------------------------------------------------------------------------------------------- */
+int sbgm_conv_pack_weight_dgrad(const float* w_oihw, float* packed, int Cout, int Cin, int KH, int KW, void* stream);
+/* dW (OIHW) = sum_p dy[p,:] (x) x[p@tap,:]; ws: >= KH*KW*Cout*c_pad floats */
+int sbgm_conv2d_wgrad(const float* dy, const float* x, float* dw_oihw, float* ws, int B, int H, int W, int c_pad, int Cin,
+                      int Cout, int KH, int KW, int stride, int pad, void* stream);
+int sbgm_colsum(const float* x, const float* y /* NULL or multiplied elementwise */, float* out, int M, int C, void* stream);
+int sbgm_samplesum(const float* x, float* out /* [B,C] */, int B, int HW, int C, void* stream);
+/* ws: >= 8*B*C bytes */
+int sbgm_groupnorm_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* skip,
+                       const float* tbias, const float* mean_rstd, int act, float* dx, float* dskip, float* dgamma,
+                       float* dbeta, float* dtbias, float* ws, int B, int HW, int C, int G, void* stream);
+int sbgm_batchnorm_bwd(const float* x, const float* dy, const float* y, const float* gamma, const float* tbias_after,
+                       const float* mean_rstd /* [C,2] */, int relu, float* dx, float* dres, float* dgamma, float* dbeta,
+                       float* ws, int B, int HW, int C, void* stream);
+int sbgm_layernorm_bwd(const float* x, const float* dy, const float* gamma, float* dx, float* dgamma, float* dbeta, int M,
+                       int C, float eps, void* stream);
+int sbgm_mha_core_bwd(const float* qkv, const float* dout, float* dqkv, int B, int S, int C, int heads, void* stream);
+int sbgm_upsample2x_bwd(const float* dy, float* dx, int B, int H, int W, int C, void* stream);
+int sbgm_conv3x3_cout1_bwd(const float* dout, const float* a, const float* w_tap_c, const float* t, float sigma, float* da,
+                           float* dw_tap_c, float* dbias, int B, int H, int W, int C, void* stream);
+int sbgm_time_proj_bwd(const float* dout, const float* weight, const float* semb, const float* emb_raw, float* dW,
+                       float* dbias, float* demb_accum /* NULL or [B,D], accumulated */, int B, int D, int ch, void* stream);
+int sbgm_label_emb_bwd(const float* demb, const int64_t* y, float* dtable, int B, int D, void* stream);
+int sbgm_act_fwd(const float* x, float* y, int64_t n, int act, void* stream);
+int sbgm_act_bwd(const float* x, const float* dy, float* dx, int64_t n, int act, void* stream);
 
 /* Sampler updates with explicit scalars (the fused loop above uses a device-side table instead).
  * z NULL -> Philox draw keyed by (seed, draw_index).

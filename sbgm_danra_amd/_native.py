@@ -42,7 +42,8 @@ class ConvArgs(C.Structure):
     _fields_ = [("x", _vp), ("w_packed", _vp), ("out", _vp), ("scale", _vp), ("bias", _vp), ("tbias", _vp),
                 ("residual", _vp), ("B", _i), ("H", _i), ("W", _i), ("c_pad", _i), ("Cout", _i), ("KH", _i), ("KW", _i),
                 ("stride", _i), ("pad", _i), ("act", _i), ("tbias_after_act", _i), ("tile_co", _i), ("tile_px", _i),
-                ("splits", _i), ("waves_per_tile", _i), ("ws", _vp), ("ws_floats", _i64)]
+                ("splits", _i), ("waves_per_tile", _i), ("in_dil", _i), ("out_h", _i), ("out_w", _i), ("ws", _vp),
+                ("ws_floats", _i64)]
 
 
 # name -> (restype, argtypes); every symbol include/sbgm_hip.h declares
@@ -72,14 +73,28 @@ SIGNATURES = {
     "sbgm_conv_pack_weight": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sbgm_conv2d_fwd": (_i, [C.POINTER(ConvArgs), _vp]),
     "sbgm_upsample2x_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
-    "sbgm_groupnorm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp]),
+    "sbgm_groupnorm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "sbgm_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "sbgm_batchnorm_train_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp]),
     "sbgm_mha_core_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
-    "sbgm_time_proj_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    "sbgm_time_proj_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "sbgm_cout1_pack_weight": (_i, [_vp, _vp, _i, _vp]),
     "sbgm_conv3x3_cout1_fwd": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp]),
     "sbgm_act_inplace": (_i, [_vp, _i64, _i, _vp]),
+    "sbgm_conv_pack_weight_dgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "sbgm_conv2d_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "sbgm_colsum": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "sbgm_samplesum": (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    "sbgm_groupnorm_bwd": (_i, [_vp] * 14 + [_i, _i, _i, _i, _vp]),
+    "sbgm_batchnorm_bwd": (_i, [_vp] * 6 + [_i] + [_vp] * 5 + [_i, _i, _i, _vp]),
+    "sbgm_layernorm_bwd": (_i, [_vp] * 6 + [_i, _i, _f, _vp]),
+    "sbgm_mha_core_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "sbgm_upsample2x_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "sbgm_conv3x3_cout1_bwd": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    "sbgm_time_proj_bwd": (_i, [_vp] * 7 + [_i, _i, _i, _vp]),
+    "sbgm_label_emb_bwd": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
+    "sbgm_act_fwd": (_i, [_vp, _vp, _i64, _i, _vp]),
+    "sbgm_act_bwd": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
     "sbgm_em_step": (_i, [_vp, _vp, _vp, _vp, _f, _f, _f, _u64, _u64, _i64, _vp]),
     "sbgm_langevin_step": (_i, [_vp, _vp, _vp, _f, _vp, _u64, _u64, _i, _i64, _vp]),
     "sbgm_cfg_combine": (_i, [_vp, _vp, _vp, _f, _i64, _vp]),

@@ -1,0 +1,683 @@
+// Backward kernels of the training path (reference: everything `loss.backward()` differentiates in
+// sbgm/training.py:403-405, i.e. the autograd of the ops in sbgm/score_unet.py).  Data-gradients of the
+// convolutions reuse conv_igemm.hip with transposed/flipped packed weights; this file holds the weight-gradient
+// GEMM, the normalisation / attention / resampling backward passes and the small reductions.
+// First version: correct and parity-tested; only the weight-gradient kernel is on the MFMA pipe.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+inline int stream_blocks(size_t n, int cap = 2048) { return (int)std::min<size_t>((n + 255) / 256, (size_t)cap); }
+
+// =====================================================================================================================
+// Convolution weight gradient:  dW[tap][co][ci] += sum_p dy[p][co] * x[p @ tap][ci]        (fp32 MFMA 16x16x4)
+// GEMM roles: rows = output channels, cols = input channels, K = pixels.  A lane's 16-byte dy load holds 4 CHANNELS of
+// one pixel, so MFMA i of a group uses element i and owns the rows {4r+i}: 4 accumulator sets cover 64 channels, the
+// K index of the instruction is the pixel (lane>>4).  x is read one dword per lane (16 consecutive channels of the
+// tap-shifted pixel).  Workgroups split the pixel range; partial sums are combined with fp32 atomics.
+// =====================================================================================================================
+template <int FCI>   // 16*FCI input channels per wave
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                         float* __restrict__ dwp, int B, int H, int W, int Cs, int OH,
+                                                         int OW, int Cout, int KH, int KW, int S, int PAD, int px_per_split) {
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int n_ci_t = (Cs + 16 * FCI - 1) / (16 * FCI), n_co_t = Cout / 64;
+    int tile = blockIdx.x * 4 + wave;
+    if (tile >= KH * KW * n_co_t * n_ci_t) return;
+    const int ci_t = tile % n_ci_t; tile /= n_ci_t;
+    const int co_t = tile % n_co_t; tile /= n_co_t;
+    const int tap = tile;
+    const int kh = tap / KW, kw = tap - kh * KW;
+    const int co0 = co_t * 64, ci0 = ci_t * 16 * FCI;
+    const int M = B * OH * OW;
+    const int p_begin = blockIdx.y * px_per_split;
+    const int p_end = min(M, p_begin + px_per_split);
+
+    f32x4 acc[4][FCI];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < FCI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int p0 = p_begin; p0 < p_end; p0 += 4) {
+        const int p = p0 + kq;                                   // this lane's pixel (the MFMA k index)
+        f32x4 a = {0.f, 0.f, 0.f, 0.f};
+        float bv[FCI];
+#pragma unroll
+        for (int j = 0; j < FCI; ++j) bv[j] = 0.f;
+        if (p < p_end) {
+            a = *reinterpret_cast<const f32x4*>(dy + (size_t)p * Cout + co0 + 4 * r16);
+            const int b = p / (OH * OW);
+            const int rr = p - b * OH * OW;
+            const int oy = rr / OW, ox = rr - oy * OW;
+            const int iy = oy * S - PAD + kh, ix = ox * S - PAD + kw;
+            if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+                const float* xp = x + (((size_t)b * H + iy) * W + ix) * Cs + ci0 + r16;
+#pragma unroll
+                for (int j = 0; j < FCI; ++j)
+                    if (ci0 + 16 * j + r16 < Cs) bv[j] = xp[16 * j];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < FCI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bv[j], acc[i][j], 0, 0, 0);
+    }
+    // D_i[row][col]: row = 4*kq + reg -> channel co0 + 4*row + i ; col = r16 -> ci0 + 16j + r16
+    float* base = dwp + ((size_t)tap * Cout) * Cs;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < FCI; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int co = co0 + 4 * (4 * kq + e) + i;
+                if (ci0 + 16 * j + r16 < Cs) atomicAdd(base + (size_t)co * Cs + ci0 + 16 * j + r16, acc[i][j][e]);
+            }
+}
+
+// dwp [tap][Cout][Cs] -> OIHW [Cout][Cin][KH][KW]
+__global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int Cout, int Cin, int Cs, int taps) {
+    const size_t total = (size_t)Cout * Cin * taps;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int tap = (int)(i % taps);
+        const int ci = (int)((i / taps) % Cin);
+        const int co = (int)(i / ((size_t)taps * Cin));
+        dw[i] = dwp[((size_t)tap * Cout + co) * Cs + ci];
+    }
+}
+
+// =====================================================================================================================
+// Small reductions.  colsum: out[c] (+)= sum_m x[m][c] (* y[m][c]);  samplesum: out[b][c] = sum_px x[b][px][c]
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                     float* __restrict__ out, int M, int C, int rows_per_block) {
+    // thread -> channel (coalesced along C), loop over rows of this block's slab, one atomic per (block, channel)
+    const int r0 = blockIdx.y * rows_per_block, r1 = min(M, r0 + rows_per_block);
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < C; c += gridDim.x * blockDim.x) {
+        float s = 0.f;
+        for (int m = r0; m < r1; ++m) s += y ? x[(size_t)m * C + c] * y[(size_t)m * C + c] : x[(size_t)m * C + c];
+        atomicAdd(out + c, s);
+    }
+}
+
+// =====================================================================================================================
+// Normalisation backward.  Shared structure: pass 1 reduces, per (sample, channel), s1 = sum g and s2 = sum g*xhat over
+// the pixels (g = upstream gradient after the activation / ReLU mask); pass 2 forms dx from group (or batch) means.
+// =====================================================================================================================
+struct NormBwdArgs {
+    const float* x;        // [B][HW][C] input of the normalisation (conv output)
+    const float* dy;       // [B][HW][C] upstream gradient
+    const float* y;        // output of the fused op (for the ReLU mask of BatchNorm) or null
+    const float* gamma;    // [C] or null
+    const float* beta;     // [C] or null
+    const float* skip;     // GroupNorm: residual added before the activation, or null
+    const float* tbias;    // [B][C] time bias added before the activation (GroupNorm) / after ReLU (BatchNorm), or null
+    const float* mr;       // statistics: GroupNorm [B][G][2] (mean, rstd); BatchNorm [C][2]
+    float* dx;             // [B][HW][C]
+    float* dres;           // gradient w.r.t. skip / residual, or null
+    float* s12;            // workspace [B][C][2] (zeroed by the launcher)
+    int B, HW, C, G, act, relu, has_res;
+};
+
+__device__ __forceinline__ float act_grad(float u, int act) {
+    switch (act) {
+        case SBGM_ACT_RELU: return u > 0.f ? 1.f : 0.f;
+        case SBGM_ACT_SILU: { const float s = 1.f / (1.f + expf(-u)); return s * (1.f + u * (1.f - s)); }
+        case SBGM_ACT_GELU: return 0.5f * (1.f + erff(u * 0.70710678118654752440f)) + u * 0.39894228040143267794f * expf(-0.5f * u * u);
+        default: return 1.f;
+    }
+}
+
+// GroupNorm: u = xhat*gamma + beta + skip + tbias ; y = act(u).  g = dy * act'(u).
+template <bool BATCHNORM>
+__global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(NormBwdArgs a, int px_per_block) {
+    const int b = blockIdx.y;
+    const int cq = a.C >> 2, cpg = a.C / a.G;
+    const int q = threadIdx.x % cq, stripe = threadIdx.x / cq, lanes_px = 256 / cq;
+    if (stripe >= lanes_px) return;
+    const int c = q * 4;
+    const int p0 = blockIdx.x * px_per_block, p1 = min(a.HW, p0 + px_per_block);
+    f32x4 mean, rstd, gam = {1.f, 1.f, 1.f, 1.f}, bet = {0.f, 0.f, 0.f, 0.f}, tb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int si = BATCHNORM ? (c + e) : (b * a.G + (c + e) / cpg);
+        mean[e] = a.mr[2 * si];
+        rstd[e] = a.mr[2 * si + 1];
+    }
+    if (a.gamma) { gam = *reinterpret_cast<const f32x4*>(a.gamma + c); bet = *reinterpret_cast<const f32x4*>(a.beta + c); }
+    if (a.tbias) tb = *reinterpret_cast<const f32x4*>(a.tbias + (size_t)b * a.C + c);
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
+    const size_t base = (size_t)b * a.HW * a.C + c;
+    for (int p = p0 + stripe; p < p1; p += lanes_px) {
+        const size_t o = base + (size_t)p * a.C;
+        const f32x4 xh = (*reinterpret_cast<const f32x4*>(a.x + o) - mean) * rstd;
+        f32x4 g = *reinterpret_cast<const f32x4*>(a.dy + o);
+        if (BATCHNORM) {
+            if (a.relu) {
+                f32x4 yv = *reinterpret_cast<const f32x4*>(a.y + o);
+                if (a.tbias) yv -= tb;                      // y = relu(.) + tbias  ->  relu output = y - tbias
+#pragma unroll
+                for (int e = 0; e < 4; ++e) g[e] = yv[e] > 0.f ? g[e] : 0.f;
+            }
+        } else if (a.act != SBGM_ACT_NONE) {
+            f32x4 u = xh * gam + bet + tb;
+            if (a.skip) u += *reinterpret_cast<const f32x4*>(a.skip + o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] *= act_grad(u[e], a.act);
+        }
+        s1 += g;
+        s2 += g * xh;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        atomicAdd(a.s12 + ((size_t)b * a.C + c + e) * 2, s1[e]);
+        atomicAdd(a.s12 + ((size_t)b * a.C + c + e) * 2 + 1, s2[e]);
+    }
+}
+
+// pass 2: dx = rstd * (g*gamma - mean_set(g*gamma) - xhat * mean_set(g*gamma*xhat)); dres = g
+template <bool BATCHNORM>
+__global__ __launch_bounds__(256) void norm_bwd_apply_kernel(NormBwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* m12 = reinterpret_cast<float*>(smem_raw);       // per channel: mean over the set of g*gamma and g*gamma*xhat
+    const int b = blockIdx.y;
+    const int cq = a.C >> 2, cpg = a.C / a.G;
+    if (BATCHNORM) {
+        const float inv_n = 1.f / ((float)a.B * a.HW);
+        for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
+            float t1 = 0.f, t2 = 0.f;
+            for (int bb = 0; bb < a.B; ++bb) { t1 += a.s12[((size_t)bb * a.C + c) * 2]; t2 += a.s12[((size_t)bb * a.C + c) * 2 + 1]; }
+            m12[2 * c] = t1 * inv_n;                         // gamma factors out per channel for BatchNorm
+            m12[2 * c + 1] = t2 * inv_n;
+        }
+    } else {
+        const float inv_n = 1.f / ((float)a.HW * cpg);
+        for (int g = threadIdx.x; g < a.G; g += blockDim.x) {
+            float t1 = 0.f, t2 = 0.f;
+            for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+                const float gm = a.gamma ? a.gamma[c] : 1.f;
+                t1 += gm * a.s12[((size_t)b * a.C + c) * 2];
+                t2 += gm * a.s12[((size_t)b * a.C + c) * 2 + 1];
+            }
+            for (int c = g * cpg; c < (g + 1) * cpg; ++c) { m12[2 * c] = t1 * inv_n; m12[2 * c + 1] = t2 * inv_n; }
+        }
+    }
+    __syncthreads();
+    const size_t per_sample = (size_t)a.HW * cq;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_sample; i += (size_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cq) * 4;
+        const size_t o = (size_t)b * a.HW * a.C + i * 4;
+        f32x4 g = *reinterpret_cast<const f32x4*>(a.dy + o);
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(a.x + o);
+        f32x4 dxv;
+        f32x4 tb = {0.f, 0.f, 0.f, 0.f};
+        if (a.tbias) tb = *reinterpret_cast<const f32x4*>(a.tbias + (size_t)b * a.C + c);
+        f32x4 yv = {1.f, 1.f, 1.f, 1.f}, sk = {0.f, 0.f, 0.f, 0.f};
+        if (BATCHNORM && a.relu) { yv = *reinterpret_cast<const f32x4*>(a.y + o); if (a.tbias) yv -= tb; }
+        if (!BATCHNORM && a.skip) sk = *reinterpret_cast<const f32x4*>(a.skip + o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int si = BATCHNORM ? (c + e) : (b * a.G + (c + e) / cpg);
+            const float mean = a.mr[2 * si], rstd = a.mr[2 * si + 1];
+            const float gm = a.gamma ? a.gamma[c + e] : 1.f;
+            const float xh = (xv[e] - mean) * rstd;
+            if (BATCHNORM) {
+                if (a.relu && !(yv[e] > 0.f)) g[e] = 0.f;
+                dxv[e] = gm * rstd * (g[e] - m12[2 * (c + e)] - xh * m12[2 * (c + e) + 1]);
+            } else {
+                if (a.act != SBGM_ACT_NONE) {
+                    const float u = xh * gm + (a.beta ? a.beta[c + e] : 0.f) + sk[e] + tb[e];
+                    g[e] *= act_grad(u, a.act);
+                }
+                dxv[e] = rstd * (g[e] * gm - m12[2 * (c + e)] - xh * m12[2 * (c + e) + 1]);
+            }
+        }
+        *reinterpret_cast<f32x4*>(a.dx + o) = dxv;
+        if (a.dres) *reinterpret_cast<f32x4*>(a.dres + o) = g;
+    }
+}
+
+// from s12 [B][C][2]: dgamma[c] = sum_b s2, dbeta[c] = sum_b s1, dtbias[b][c] = s1 (GroupNorm: time bias sits inside act)
+__global__ void norm_bwd_params_kernel(const float* __restrict__ s12, float* dgamma, float* dbeta, float* dtbias, int B, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float t1 = 0.f, t2 = 0.f;
+    for (int b = 0; b < B; ++b) {
+        const float v1 = s12[((size_t)b * C + c) * 2];
+        t1 += v1;
+        t2 += s12[((size_t)b * C + c) * 2 + 1];
+        if (dtbias) dtbias[(size_t)b * C + c] = v1;
+    }
+    if (dgamma) dgamma[c] = t2;
+    if (dbeta) dbeta[c] = t1;
+}
+
+// out[b][c] = sum_px x[b][px][c]   (time-bias gradients that sit OUTSIDE an activation: conv1 and BatchNorm-late adds)
+__global__ __launch_bounds__(256) void samplesum_kernel(const float* __restrict__ x, float* __restrict__ out, int HW, int C,
+                                                        int px_per_block) {
+    const int b = blockIdx.y;
+    const int p0 = blockIdx.x * px_per_block, p1 = min(HW, p0 + px_per_block);
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float s = 0.f;
+        for (int p = p0; p < p1; ++p) s += x[((size_t)b * HW + p) * C + c];
+        atomicAdd(out + (size_t)b * C + c, s);
+    }
+}
+
+// LayerNorm backward, one wave per token: dx = rstd*(g*gamma - mean(g*gamma) - xhat*mean(g*gamma*xhat));
+// dgamma/dbeta accumulated with atomics (token counts are small here: <= B*1024).
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                            const float* __restrict__ gamma, float* __restrict__ dx,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int C,
+                                                            float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    if (row >= M) return;
+    const float* xr = x + (size_t)row * C;
+    const float* gr = dy + (size_t)row * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += xr[c];
+    const float mean = wave_sum(s) / (float)C;
+    float s2 = 0.f;
+    for (int c = lane; c < C; c += 64) { const float d = xr[c] - mean; s2 += d * d; }
+    const float rstd = 1.f / sqrtf(wave_sum(s2) / (float)C + eps);
+    float a1 = 0.f, a2 = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float xh = (xr[c] - mean) * rstd, gg = gr[c] * gamma[c];
+        a1 += gg;
+        a2 += gg * xh;
+    }
+    a1 = wave_sum(a1) / (float)C;
+    a2 = wave_sum(a2) / (float)C;
+    for (int c = lane; c < C; c += 64) {
+        const float xh = (xr[c] - mean) * rstd;
+        dx[(size_t)row * C + c] = rstd * (gr[c] * gamma[c] - a1 - xh * a2);
+        atomicAdd(dgamma + c, gr[c] * xh);
+        atomicAdd(dbeta + c, gr[c]);
+    }
+}
+
+// =====================================================================================================================
+// Attention core backward.  One workgroup per (sample, head, block of 16 queries); 16 lanes per query.
+//   P = softmax(q k^T * scale);  dV += P^T dO;  dP = dO V^T;  dS = P*(dP - sum_j P dP);  dQ = dS K * scale;  dK += dS^T Q * scale
+// dK/dV are accumulated with fp32 atomics (every query block contributes to all keys).
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void mha_core_bwd_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                           float* __restrict__ dqkv, int B, int S, int C, int heads, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* Pm = reinterpret_cast<float*>(smem_raw);      // [16][S]
+    float* dSm = Pm + 16 * S;                            // [16][S]
+    const int d = C / heads;
+    const int qblocks = (S + 15) / 16;
+    int w = blockIdx.x;
+    const int qb = w % qblocks; w /= qblocks;
+    const int h = w % heads;
+    const int b = w / heads;
+    const int qi_l = threadIdx.x >> 4, sub = threadIdx.x & 15;
+    const int qi = qb * 16 + qi_l;
+    const bool q_ok = qi < S;
+    const size_t rs = 3 * (size_t)C;
+    const float* base = qkv + (size_t)b * S * rs + (size_t)h * d;
+    float* dbase = dqkv + (size_t)b * S * rs + (size_t)h * d;
+    const float* qrow = base + (size_t)(q_ok ? qi : 0) * rs;
+    const float* dorow = dout + ((size_t)b * S + (q_ok ? qi : 0)) * C + (size_t)h * d;
+    // scores + softmax
+    float mx = -INFINITY;
+    for (int j = sub; j < S; j += 16) {
+        const float* kr = base + (size_t)j * rs + C;
+        float s = 0.f;
+        for (int e = 0; e < d; ++e) s = fmaf(qrow[e], kr[e], s);
+        s *= scale;
+        Pm[qi_l * S + j] = s;
+        mx = fmaxf(mx, s);
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    float sum = 0.f;
+    for (int j = sub; j < S; j += 16) { const float p = expf(Pm[qi_l * S + j] - mx); Pm[qi_l * S + j] = p; sum += p; }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    const float inv = 1.f / sum;
+    float delta = 0.f;
+    for (int j = sub; j < S; j += 16) {
+        const float p = Pm[qi_l * S + j] * inv;
+        const float* vr = base + (size_t)j * rs + 2 * C;
+        float dp = 0.f;
+        for (int e = 0; e < d; ++e) dp = fmaf(dorow[e], vr[e], dp);
+        Pm[qi_l * S + j] = p;
+        dSm[qi_l * S + j] = dp;
+        delta += p * dp;
+    }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) delta += __shfl_xor(delta, o, 64);
+    for (int j = sub; j < S; j += 16) {
+        const float ds = q_ok ? Pm[qi_l * S + j] * (dSm[qi_l * S + j] - delta) * scale : 0.f;
+        dSm[qi_l * S + j] = ds;
+        if (!q_ok) Pm[qi_l * S + j] = 0.f;
+    }
+    __syncthreads();
+    // dQ[qi][e] = sum_j dS[qi][j] K[j][e]      (16 lanes of a query stride over e)
+    if (q_ok) {
+        for (int e = sub; e < d; e += 16) {
+            float acc = 0.f;
+            for (int j = 0; j < S; ++j) acc = fmaf(dSm[qi_l * S + j], base[(size_t)j * rs + C + e], acc);
+            dbase[(size_t)qi * rs + e] = acc;
+        }
+    }
+    // dK[j][e] += sum_i dS[i][j] Q[i][e] ;  dV[j][e] += sum_i P[i][j] dO[i][e]      (threads stride over (j, e))
+    const int nq = min(16, S - qb * 16);
+    for (int idx = threadIdx.x; idx < S * d; idx += blockDim.x) {
+        const int j = idx / d, e = idx - j * d;
+        float ak = 0.f, av = 0.f;
+        for (int i = 0; i < nq; ++i) {
+            const int qq = qb * 16 + i;
+            ak = fmaf(dSm[i * S + j], base[(size_t)qq * rs + e], ak);
+            av = fmaf(Pm[i * S + j], dout[((size_t)b * S + qq) * C + (size_t)h * d + e], av);
+        }
+        atomicAdd(dbase + (size_t)j * rs + C + e, ak);
+        atomicAdd(dbase + (size_t)j * rs + 2 * C + e, av);
+    }
+}
+
+// =====================================================================================================================
+// Bilinear x2 (align_corners=False) backward as a gather: each input pixel collects its <= 4x4 output pixels.
+// 1-D weights of input y from outputs 2y-1 (.25), 2y (.75, or 1 at y=0), 2y+1 (.75, or 1 at y=H-1), 2y+2 (.25).
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int B, int H,
+                                                             int W, int C) {
+    const int cq = C >> 2, OH = 2 * H, OW = 2 * W;
+    const size_t total = (size_t)B * H * W * cq;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % cq);
+        size_t r = i / cq;
+        const int x = (int)(r % W); r /= W;
+        const int y = (int)(r % H);
+        const int b = (int)(r / H);
+        const float wy[4] = {y >= 1 ? 0.25f : 0.f, y == 0 ? 1.f : 0.75f, y == H - 1 ? 1.f : 0.75f, y <= H - 2 ? 0.25f : 0.f};
+        const float wx[4] = {x >= 1 ? 0.25f : 0.f, x == 0 ? 1.f : 0.75f, x == W - 1 ? 1.f : 0.75f, x <= W - 2 ? 0.25f : 0.f};
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const int oy = 2 * y - 1 + a;
+            if (wy[a] == 0.f || oy < 0 || oy >= OH) continue;
+#pragma unroll
+            for (int c2 = 0; c2 < 4; ++c2) {
+                const int ox = 2 * x - 1 + c2;
+                if (wx[c2] == 0.f || ox < 0 || ox >= OW) continue;
+                acc += (wy[a] * wx[c2]) * *reinterpret_cast<const f32x4*>(dy + (((size_t)b * OH + oy) * OW + ox) * C + q * 4);
+            }
+        }
+        *reinterpret_cast<f32x4*>(dx + i * 4) = acc;
+    }
+}
+
+// =====================================================================================================================
+// final_layer.conv (3x3, C -> 1) + /sigma(t) backward.  g[p] = dout[p] / sigma(t_b).
+//   da[p][c] = sum_tap w[tap][c] * g[p - off(tap)] ;  dw[tap][c] = sum_p a[p + off(tap)][c] * g[p] ;  dbias = sum_p g[p]
+// =====================================================================================================================
+__device__ __forceinline__ float sigma_of(float t, float sigma) {
+    const float ls = logf(sigma);
+    return fmaxf(sqrtf((expf((2.f * t) * ls) - 1.f) / (2.f * ls)), 1e-5f);
+}
+
+__global__ __launch_bounds__(256) void cout1_bwd_data_kernel(const float* __restrict__ dout, const float* __restrict__ w,
+                                                             const float* __restrict__ t, float sigma, float* __restrict__ da,
+                                                             int B, int H, int W, int C) {
+    const int cq = C >> 2;
+    const size_t total = (size_t)B * H * W * cq;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % cq);
+        size_t r = i / cq;
+        const int x = (int)(r % W); r /= W;
+        const int y = (int)(r % H);
+        const int b = (int)(r / H);
+        const float inv = t ? 1.f / sigma_of(t[b], sigma) : 1.f;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int oy = y - (kh - 1);                 // output pixel whose tap (kh,kw) reads input (y,x)
+            if ((unsigned)oy >= (unsigned)H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int ox = x - (kw - 1);
+                if ((unsigned)ox >= (unsigned)W) continue;
+                acc += (dout[((size_t)b * H + oy) * W + ox] * inv) * *reinterpret_cast<const f32x4*>(w + (kh * 3 + kw) * C + q * 4);
+            }
+        }
+        *reinterpret_cast<f32x4*>(da + i * 4) = acc;
+    }
+}
+
+// one block per (row-slab): accumulates dw[9][C] and dbias with atomics
+__global__ __launch_bounds__(256) void cout1_bwd_weight_kernel(const float* __restrict__ dout, const float* __restrict__ a,
+                                                               const float* __restrict__ t, float sigma, float* __restrict__ dw,
+                                                               float* __restrict__ dbias, int B, int H, int W, int C,
+                                                               int rows_per_block) {
+    const int nrows = B * H;
+    const int r0 = blockIdx.x * rows_per_block, r1 = min(nrows, r0 + rows_per_block);
+    for (int idx = threadIdx.x; idx < 9 * C; idx += blockDim.x) {
+        const int tap = idx / C, c = idx - tap * C;
+        const int kh = tap / 3, kw = tap - kh * 3;
+        float s = 0.f;
+        for (int row = r0; row < r1; ++row) {
+            const int b = row / H, oy = row - b * H;
+            const int iy = oy + kh - 1;
+            if ((unsigned)iy >= (unsigned)H) continue;
+            const float inv = t ? 1.f / sigma_of(t[b], sigma) : 1.f;
+            for (int ox = 0; ox < W; ++ox) {
+                const int ix = ox + kw - 1;
+                if ((unsigned)ix >= (unsigned)W) continue;
+                s = fmaf(a[(((size_t)b * H + iy) * W + ix) * C + c], dout[(size_t)row * W + ox] * inv, s);
+            }
+        }
+        atomicAdd(dw + idx, s);
+    }
+    if (threadIdx.x < 64) {
+        float s = 0.f;
+        for (int row = r0; row < r1; ++row) {
+            const float inv = t ? 1.f / sigma_of(t[row / H], sigma) : 1.f;
+            for (int ox = threadIdx.x; ox < W; ox += 64) s += dout[(size_t)row * W + ox] * inv;
+        }
+        s = wave_sum(s);
+        if (threadIdx.x == 0) atomicAdd(dbias, s);
+    }
+}
+
+// =====================================================================================================================
+// Time projection backward: out[b][c] = bias[c] + sum_d W[c][d]*semb[b][d], semb = silu(emb).
+//   dW[c][d] = sum_b dout[b][c]*semb[b][d]; dbias[c] = sum_b dout[b][c]; demb[b][d] += silu'(emb[b][d]) * sum_c dout[b][c] W[c][d]
+// =====================================================================================================================
+__global__ __launch_bounds__(256) void time_proj_bwd_w_kernel(const float* __restrict__ dout, const float* __restrict__ semb,
+                                                              float* __restrict__ dW, float* __restrict__ dbias, int B, int D, int ch) {
+    const size_t total = (size_t)ch * D;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int dd = (int)(i % D), c = (int)(i / D);
+        float s = 0.f, sb = 0.f;
+        for (int b = 0; b < B; ++b) { const float g = dout[(size_t)b * ch + c]; s = fmaf(g, semb[(size_t)b * D + dd], s); sb += g; }
+        dW[i] = s;
+        if (dd == 0) dbias[c] = sb;
+    }
+}
+// demb_pre[b][d] (+)= silu'(emb) * sum_c dout[b][c] W[c][d]   (emb recovered from `emb_raw` = pre-SiLU embedding)
+__global__ __launch_bounds__(256) void time_proj_bwd_e_kernel(const float* __restrict__ dout, const float* __restrict__ Wt,
+                                                              const float* __restrict__ emb_raw, float* __restrict__ demb, int B,
+                                                              int D, int ch) {
+    const int total = B * D;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int dd = i % D, b = i / D;
+        float s = 0.f;
+        for (int c = 0; c < ch; ++c) s = fmaf(dout[(size_t)b * ch + c], Wt[(size_t)c * D + dd], s);
+        demb[i] += s * act_grad(emb_raw[i], SBGM_ACT_SILU);
+    }
+}
+// label embedding gradient: dtable[y[b]][d] += demb[b][d]
+__global__ void label_emb_bwd_kernel(const float* __restrict__ demb, const int64_t* __restrict__ y, float* __restrict__ dtable, int B, int D) {
+    const int total = B * D;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x)
+        atomicAdd(dtable + (size_t)y[i / D] * D + (i % D), demb[i]);
+}
+
+// dx = dy * act'(x)   (GELU between the attention FF linears)
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ dx,
+                                                      size_t n, int act) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        dx[i] = dy[i] * act_grad(x[i], act);
+}
+
+// y = act(x) out of place (training keeps the pre-activation)
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, float* __restrict__ y, size_t n, int act) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) y[i] = sbgm_act(x[i], act);
+}
+
+}  // namespace
+
+// ---- launchers -----------------------------------------------------------------------------------------------------
+int sbgm_launch_conv_wgrad(const float* dy, const float* x, float* dw_oihw, float* dwp_ws, int B, int H, int W, int Cs, int Cin,
+                           int Cout, int KH, int KW, int S, int PAD, hipStream_t st) {
+    SBGM_CHECK(Cout % 64 == 0, "wgrad: Cout=%d must be a multiple of 64", Cout);
+    SBGM_CHECK((Cs == 4 || Cs == 8 || Cs % 16 == 0) && Cin <= Cs, "wgrad: padded Cin %d unsupported (Cin=%d)", Cs, Cin);
+    const int OH = (H + 2 * PAD - KH) / S + 1, OW = (W + 2 * PAD - KW) / S + 1, M = B * OH * OW;
+    const int fci = Cs % 64 == 0 ? 4 : (Cs % 32 == 0 ? 2 : 1);
+    const int tiles = KH * KW * (Cout / 64) * ((Cs + 16 * fci - 1) / (16 * fci));
+    int splits = std::max(1, std::min((M + 63) / 64, (4096 + tiles - 1) / tiles));
+    int pps = ((M + splits - 1) / splits + 3) / 4 * 4;
+    splits = (M + pps - 1) / pps;
+    const size_t n = (size_t)KH * KW * Cout * Cs;
+    SBGM_HIP(hipMemsetAsync(dwp_ws, 0, n * 4, st));
+    dim3 grid((tiles + 3) / 4, splits);
+#define SBGM_WG(F) hipLaunchKernelGGL(conv_wgrad_kernel<F>, grid, dim3(256), 0, st, dy, x, dwp_ws, B, H, W, Cs, OH, OW, Cout, KH, KW, S, PAD, pps)
+    if (fci == 4) SBGM_WG(4); else if (fci == 2) SBGM_WG(2); else SBGM_WG(1);
+#undef SBGM_WG
+    SBGM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(stream_blocks((size_t)Cout * Cin * KH * KW)), dim3(256), 0, st, dwp_ws, dw_oihw, Cout,
+                       Cin, Cs, KH * KW);
+    SBGM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sbgm_launch_colsum(const float* x, const float* y, float* out, int M, int C, hipStream_t st) {
+    SBGM_HIP(hipMemsetAsync(out, 0, (size_t)C * 4, st));
+    const int slabs = std::max(1, std::min(512, M / 64));
+    const int rpb = (M + slabs - 1) / slabs;
+    hipLaunchKernelGGL(colsum_kernel, dim3((C + 255) / 256, (M + rpb - 1) / rpb), dim3(256), 0, st, x, y, out, M, C, rpb);
+    SBGM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sbgm_launch_samplesum(const float* x, float* out, int B, int HW, int C, hipStream_t st) {
+    SBGM_HIP(hipMemsetAsync(out, 0, (size_t)B * C * 4, st));
+    const int chunks = std::max(1, std::min(64, HW / 64));
+    const int ppb = (HW + chunks - 1) / chunks;
+    hipLaunchKernelGGL(samplesum_kernel, dim3((HW + ppb - 1) / ppb, B), dim3(256), 0, st, x, out, HW, C, ppb);
+    SBGM_LAUNCH_CHECK();
+    return 0;
+}
+
+static int norm_bwd(bool bn, NormBwdArgs a, float* dgamma, float* dbeta, float* dtbias, hipStream_t st) {
+    SBGM_CHECK(a.C % 4 == 0 && a.C <= 1024, "norm_bwd: C=%d unsupported", a.C);
+    SBGM_HIP(hipMemsetAsync(a.s12, 0, (size_t)a.B * a.C * 2 * 4, st));
+    const int lanes_px = std::max(1, 256 / (a.C / 4));
+    int chunks = std::max(1, std::min(64, a.HW / (lanes_px * 16)));
+    const int ppb = (a.HW + chunks - 1) / chunks;
+    chunks = (a.HW + ppb - 1) / ppb;
+    if (bn) hipLaunchKernelGGL(norm_bwd_reduce_kernel<true>, dim3(chunks, a.B), dim3(256), 0, st, a, ppb);
+    else hipLaunchKernelGGL(norm_bwd_reduce_kernel<false>, dim3(chunks, a.B), dim3(256), 0, st, a, ppb);
+    SBGM_LAUNCH_CHECK();
+    const size_t per_sample = (size_t)a.HW * (a.C / 4);
+    const int bx = (int)std::max<size_t>(1, std::min<size_t>((per_sample + 255) / 256, 2048 / std::max(1, a.B) + 1));
+    if (bn) hipLaunchKernelGGL(norm_bwd_apply_kernel<true>, dim3(bx, a.B), dim3(256), 2 * a.C * 4, st, a);
+    else hipLaunchKernelGGL(norm_bwd_apply_kernel<false>, dim3(bx, a.B), dim3(256), 2 * a.C * 4, st, a);
+    SBGM_LAUNCH_CHECK();
+    hipLaunchKernelGGL(norm_bwd_params_kernel, dim3((a.C + 255) / 256), dim3(256), 0, st, a.s12, dgamma, dbeta, dtbias, a.B, a.C);
+    SBGM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sbgm_launch_groupnorm_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* skip,
+                              const float* tbias, const float* mr, int act, float* dx, float* dskip, float* dgamma, float* dbeta,
+                              float* dtbias, float* s12_ws, int B, int HW, int C, int G, hipStream_t st) {
+    NormBwdArgs a{x, dy, nullptr, gamma, beta, skip, tbias, mr, dx, dskip, s12_ws, B, HW, C, G, act, 0, skip != nullptr};
+    return norm_bwd(false, a, dgamma, dbeta, dtbias, st);
+}
+
+int sbgm_launch_batchnorm_bwd(const float* x, const float* dy, const float* y, const float* gamma, const float* tbias_after,
+                              const float* mr, int relu, float* dx, float* dres, float* dgamma, float* dbeta, float* s12_ws, int B,
+                              int HW, int C, hipStream_t st) {
+    NormBwdArgs a{x, dy, y, gamma, nullptr, nullptr, tbias_after, mr, dx, dres, s12_ws, B, HW, C, 1, SBGM_ACT_NONE, relu, dres != nullptr};
+    return norm_bwd(true, a, dgamma, dbeta, nullptr, st);
+}
+
+int sbgm_launch_layernorm_bwd(const float* x, const float* dy, const float* gamma, float* dx, float* dgamma, float* dbeta, int M, int C,
+                              float eps, hipStream_t st) {
+    SBGM_HIP(hipMemsetAsync(dgamma, 0, (size_t)C * 4, st));
+    SBGM_HIP(hipMemsetAsync(dbeta, 0, (size_t)C * 4, st));
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, st, x, dy, gamma, dx, dgamma, dbeta, M, C, eps);
+    SBGM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sbgm_launch_mha_core_bwd(const float* qkv, const float* dout, float* dqkv, int B, int S, int C, int heads, hipStream_t st) {
+    SBGM_CHECK(heads > 0 && C % heads == 0, "mha_bwd: C=%d heads=%d", C, heads);
+    SBGM_CHECK((size_t)2 * 16 * S * 4 <= 150 * 1024, "mha_bwd: S=%d too long for the LDS-resident score rows", S);
+    SBGM_HIP(hipMemsetAsync(dqkv, 0, (size_t)B * S * 3 * C * 4, st));
+    const int blocks = B * heads * ((S + 15) / 16);
+    hipLaunchKernelGGL(mha_core_bwd_kernel, dim3(blocks), dim3(256), (size_t)2 * 16 * S * 4, st, qkv, dout, dqkv, B, S, C, heads,
+                       1.0f / sqrtf((float)(C / heads)));
+    SBGM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sbgm_launch_upsample2x_bwd(const float* dy, float* dx, int B, int H, int W, int C, hipStream_t st) {
+    SBGM_CHECK(C % 4 == 0, "upsample2x_bwd: C=%d", C);
+    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(stream_blocks((size_t)B * H * W * (C / 4))), dim3(256), 0, st, dy, dx, B, H, W, C);
+    SBGM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sbgm_launch_cout1_bwd(const float* dout, const float* a, const float* w_tap_c, const float* t, float sigma, float* da,
+                          float* dw_tap_c, float* dbias, int B, int H, int W, int C, hipStream_t st) {
+    SBGM_CHECK(C % 4 == 0, "cout1_bwd: C=%d", C);
+    hipLaunchKernelGGL(cout1_bwd_data_kernel, dim3(stream_blocks((size_t)B * H * W * (C / 4))), dim3(256), 0, st, dout, w_tap_c, t, sigma,
+                       da, B, H, W, C);
+    SBGM_LAUNCH_CHECK();
+    SBGM_HIP(hipMemsetAsync(dw_tap_c, 0, (size_t)9 * C * 4, st));
+    SBGM_HIP(hipMemsetAsync(dbias, 0, 4, st));
+    const int rows = B * H, rpb = std::max(1, rows / 1024);
+    hipLaunchKernelGGL(cout1_bwd_weight_kernel, dim3((rows + rpb - 1) / rpb), dim3(256), 0, st, dout, a, t, sigma, dw_tap_c, dbias, B, H,
+                       W, C, rpb);
+    SBGM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sbgm_launch_time_proj_bwd(const float* dout, const float* weight, const float* semb, const float* emb_raw, float* dW, float* dbias,
+                              float* demb_accum, int B, int D, int ch, hipStream_t st) {
+    hipLaunchKernelGGL(time_proj_bwd_w_kernel, dim3(stream_blocks((size_t)ch * D)), dim3(256), 0, st, dout, semb, dW, dbias, B, D, ch);
+    SBGM_LAUNCH_CHECK();
+    if (demb_accum) {
+        hipLaunchKernelGGL(time_proj_bwd_e_kernel, dim3((B * D + 255) / 256), dim3(256), 0, st, dout, weight, emb_raw, demb_accum, B, D, ch);
+        SBGM_LAUNCH_CHECK();
+    }
+    return 0;
+}
+
+int sbgm_launch_label_emb_bwd(const float* demb, const int64_t* y, float* dtable, int B, int D, hipStream_t st) {
+    hipLaunchKernelGGL(label_emb_bwd_kernel, dim3((B * D + 255) / 256), dim3(256), 0, st, demb, y, dtable, B, D);
+    SBGM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sbgm_launch_act_bwd(const float* x, const float* dy, float* dx, size_t n, int act, hipStream_t st) {
+    hipLaunchKernelGGL(act_bwd_kernel, dim3(stream_blocks(n)), dim3(256), 0, st, x, dy, dx, n, act);
+    SBGM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sbgm_launch_act_fwd(const float* x, float* y, size_t n, int act, hipStream_t st) {
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(stream_blocks(n)), dim3(256), 0, st, x, y, n, act);
+    SBGM_LAUNCH_CHECK();
+    return 0;
+}

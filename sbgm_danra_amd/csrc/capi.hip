@@ -37,11 +37,13 @@ int sbgm_conv2d_fwd(const sbgm_conv_args* a, void* stream) {
     p.act = a->act;
     SBGM_CHECK(a->act == SBGM_NONE || a->act == SBGM_RELU || a->act == SBGM_GELU, "conv2d: act must be none, relu or gelu");
     p.tbias_after_act = a->tbias_after_act;
+    p.in_dil = a->in_dil; p.out_h = a->out_h; p.out_w = a->out_w;
     ConvTile t{a->tile_co ? a->tile_co : (a->Cout % 64 == 0 ? 4 : 2), a->tile_px ? a->tile_px : 2, a->splits ? a->splits : 1,
                a->waves_per_tile ? a->waves_per_tile : 1};
     SBGM_CHECK(a->Cout % 32 == 0, "conv2d: Cout=%d must be a multiple of 32", a->Cout);
     if (t.splits > 1) {
-        const int OH = (a->H + 2 * a->pad - a->KH) / a->stride + 1, OW = (a->W + 2 * a->pad - a->KW) / a->stride + 1;
+        const int OH = a->out_h > 0 ? a->out_h : (a->H + 2 * a->pad - a->KH) / a->stride + 1;
+        const int OW = a->out_w > 0 ? a->out_w : (a->W + 2 * a->pad - a->KW) / a->stride + 1;
         SBGM_CHECK(a->ws && a->ws_floats >= (int64_t)t.splits * a->B * OH * OW * a->Cout, "conv2d: split-K workspace too small");
     }
     return sbgm_launch_conv(ConvGeom{a->KH, a->KW, a->stride, a->pad}, p, t, a->ws, ST);
@@ -51,8 +53,8 @@ int sbgm_upsample2x_fwd(const float* x, float* y, int B, int H, int W, int C, vo
     return sbgm_launch_upsample2x(x, y, B, H, W, C, ST);
 }
 int sbgm_groupnorm_fwd(const float* x, float* y, const float* gamma, const float* beta, const float* skip, const float* tbias,
-                       int act, int B, int HW, int C, int G, float eps, void* stats_ws, void* stream) {
-    return sbgm_launch_groupnorm(x, y, gamma, beta, skip, tbias, act, B, HW, C, G, eps, (double*)stats_ws, ST);
+                       int act, int B, int HW, int C, int G, float eps, void* stats_ws, float* mean_rstd_out, void* stream) {
+    return sbgm_launch_groupnorm(x, y, gamma, beta, skip, tbias, act, B, HW, C, G, eps, (double*)stats_ws, ST, mean_rstd_out);
 }
 int sbgm_layernorm_fwd(const float* x, float* y, const float* gamma, const float* beta, int M, int C, float eps, void* stream) {
     return sbgm_launch_layernorm(x, y, gamma, beta, M, C, eps, ST);
@@ -67,8 +69,9 @@ int sbgm_mha_core_fwd(const float* qkv, float* out, int B, int S, int C, int hea
     return sbgm_launch_mha_core(qkv, out, B, S, C, heads, ST);
 }
 int sbgm_time_proj_fwd(const float* t, const int64_t* y, const float* label_emb, const float* freqs, const float* weight,
-                       const float* bias, float* out, float* emb_ws, int B, int D, int ch, void* stream) {
+                       const float* bias, float* out, float* emb_ws, float* emb_raw, int B, int D, int ch, void* stream) {
     TimeEmbedArgs a{};
+    a.emb_raw = emb_raw;
     a.t = t; a.y = y; a.label_emb = label_emb; a.freqs[0] = freqs; a.n_emb = 1; a.n_proj = 1;
     a.proj[0] = TimeProj{weight, bias, out, ch, 0};
     a.emb_ws = emb_ws; a.B = B; a.D = D;
@@ -82,6 +85,53 @@ int sbgm_conv3x3_cout1_fwd(const float* x, const float* w_tap_c, const float* bi
     return sbgm_launch_conv3x3_cout1(x, w_tap_c, bias, t, sigma, out, B, H, W, C, ST);
 }
 int sbgm_act_inplace(float* x, int64_t n, int act, void* stream) { return sbgm_launch_act(x, (size_t)n, act, ST); }
+
+// ---- training path: backward entry points ---------------------------------------------------------------------------
+int sbgm_conv_pack_weight_dgrad(const float* w_oihw, float* packed, int Cout, int Cin, int KH, int KW, void* stream) {
+    // operator of the data gradient: Cout' = Cin, Cin' = Cout (padded to 16), taps flipped
+    return sbgm_launch_pack_conv_weight(w_oihw, packed, Cin, Cout, KH, KW, (Cout + 15) / 16 * 16, ST, 1);
+}
+int sbgm_conv2d_wgrad(const float* dy, const float* x, float* dw_oihw, float* ws, int B, int H, int W, int c_pad, int Cin, int Cout,
+                      int KH, int KW, int stride, int pad, void* stream) {
+    return sbgm_launch_conv_wgrad(dy, x, dw_oihw, ws, B, H, W, c_pad, Cin, Cout, KH, KW, stride, pad, ST);
+}
+int sbgm_colsum(const float* x, const float* y, float* out, int M, int C, void* stream) { return sbgm_launch_colsum(x, y, out, M, C, ST); }
+int sbgm_samplesum(const float* x, float* out, int B, int HW, int C, void* stream) { return sbgm_launch_samplesum(x, out, B, HW, C, ST); }
+int sbgm_groupnorm_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* skip, const float* tbias,
+                       const float* mean_rstd, int act, float* dx, float* dskip, float* dgamma, float* dbeta, float* dtbias, float* ws,
+                       int B, int HW, int C, int G, void* stream) {
+    return sbgm_launch_groupnorm_bwd(x, dy, gamma, beta, skip, tbias, mean_rstd, act, dx, dskip, dgamma, dbeta, dtbias, ws, B, HW, C, G, ST);
+}
+int sbgm_batchnorm_bwd(const float* x, const float* dy, const float* y, const float* gamma, const float* tbias_after,
+                       const float* mean_rstd, int relu, float* dx, float* dres, float* dgamma, float* dbeta, float* ws, int B, int HW,
+                       int C, void* stream) {
+    return sbgm_launch_batchnorm_bwd(x, dy, y, gamma, tbias_after, mean_rstd, relu, dx, dres, dgamma, dbeta, ws, B, HW, C, ST);
+}
+int sbgm_layernorm_bwd(const float* x, const float* dy, const float* gamma, float* dx, float* dgamma, float* dbeta, int M, int C,
+                       float eps, void* stream) {
+    return sbgm_launch_layernorm_bwd(x, dy, gamma, dx, dgamma, dbeta, M, C, eps, ST);
+}
+int sbgm_mha_core_bwd(const float* qkv, const float* dout, float* dqkv, int B, int S, int C, int heads, void* stream) {
+    return sbgm_launch_mha_core_bwd(qkv, dout, dqkv, B, S, C, heads, ST);
+}
+int sbgm_upsample2x_bwd(const float* dy, float* dx, int B, int H, int W, int C, void* stream) {
+    return sbgm_launch_upsample2x_bwd(dy, dx, B, H, W, C, ST);
+}
+int sbgm_conv3x3_cout1_bwd(const float* dout, const float* a, const float* w_tap_c, const float* t, float sigma, float* da,
+                           float* dw_tap_c, float* dbias, int B, int H, int W, int C, void* stream) {
+    return sbgm_launch_cout1_bwd(dout, a, w_tap_c, t, sigma, da, dw_tap_c, dbias, B, H, W, C, ST);
+}
+int sbgm_time_proj_bwd(const float* dout, const float* weight, const float* semb, const float* emb_raw, float* dW, float* dbias,
+                       float* demb_accum, int B, int D, int ch, void* stream) {
+    return sbgm_launch_time_proj_bwd(dout, weight, semb, emb_raw, dW, dbias, demb_accum, B, D, ch, ST);
+}
+int sbgm_label_emb_bwd(const float* demb, const int64_t* y, float* dtable, int B, int D, void* stream) {
+    return sbgm_launch_label_emb_bwd(demb, y, dtable, B, D, ST);
+}
+int sbgm_act_fwd(const float* x, float* y, int64_t n, int act, void* stream) { return sbgm_launch_act_fwd(x, y, (size_t)n, act, ST); }
+int sbgm_act_bwd(const float* x, const float* dy, float* dx, int64_t n, int act, void* stream) {
+    return sbgm_launch_act_bwd(x, dy, dx, (size_t)n, act, ST);
+}
 
 int sbgm_em_step(float* x, float* x_mean, const float* score, const float* z, float g2, float dt, float noise_coef,
                  uint64_t seed, uint64_t draw_index, int64_t n, void* stream) {

@@ -143,8 +143,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         for (int f = 0; f < FCO; ++f) fr.a[f] = buf_load4(wr, wo + (uint32_t)f * (16u * 64u));
 #pragma unroll
         for (int f = 0; f < FPX; ++f) {
-            const int iy = pl[f].y0 + st_kh, ix = pl[f].x0 + kw_lane;
-            const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+            int iy = pl[f].y0 + st_kh, ix = pl[f].x0 + kw_lane;
+            bool ok = true;
+            if (p.in_dil == 2) {          // transposed (stride-2) convolution: the source is read through a zero-inserted grid
+                ok = ((iy | ix) & 1) == 0;
+                iy >>= 1;
+                ix >>= 1;
+            }
+            ok = ok & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
             const uint32_t off = (uint32_t)((pl[f].base + iy * p.W + ix) * p.Cs + coff) * 4u;
             fr.b[f] = buf_load4(xr, ok ? off : 0x80000000u);
         }
@@ -288,8 +294,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_epilogue(const ConvParams p
 }
 
 // OIHW -> packed [step][Cout][16] (see header comment).  cs = padded input channel count.
+// `transposed` != 0: pack the data-gradient operator instead: W'[o=ci][i=co][kh][kw] = W[co][ci][KH-1-kh][KW-1-kw]
+// (Cout/Cin below are then the TRANSPOSED operator's sizes, i.e. Cout = forward Cin).
 __global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin,
-                                        int KH, int KW, int cs, int nsteps) {
+                                        int KH, int KW, int cs, int nsteps, int transposed) {
     const size_t total = (size_t)nsteps * Cout * 16;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const int k16 = (int)(i & 15);
@@ -306,7 +314,10 @@ __global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __re
             kh = s / (KW / 2); kw = (s - kh * (KW / 2)) * 2 + (k16 >> 3); c = k16 & 7;
         }
         float v = 0.f;
-        if (c < Cin) v = w[(((size_t)co * Cin + c) * KH + kh) * KW + kw];
+        if (c < Cin) {
+            if (!transposed) v = w[(((size_t)co * Cin + c) * KH + kh) * KW + kw];
+            else v = w[(((size_t)c * Cout + co) * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)];   // forward layout [Cin'][Cout'] = [c][co]
+        }
         wp[i] = v;
     }
 }
@@ -334,14 +345,15 @@ int sbgm_conv_nsteps(int KH, int KW, int cs) {
 }
 
 int sbgm_launch_pack_conv_weight(const float* w_oihw, float* wp, int Cout, int Cin, int KH, int KW, int cs,
-                                 hipStream_t st) {
+                                 hipStream_t st, int transposed) {
     SBGM_CHECK(cs == 4 || cs == 8 || (cs >= 16 && cs % 16 == 0), "pack_conv_weight: bad padded Cin %d", cs);
     SBGM_CHECK(cs >= 16 || KW % (16 / cs) == 0, "pack_conv_weight: KW=%d not divisible for cs=%d", KW, cs);
     SBGM_CHECK(Cin <= cs, "pack_conv_weight: Cin %d > padded %d", Cin, cs);
     const int nsteps = sbgm_conv_nsteps(KH, KW, cs);
     const size_t total = (size_t)nsteps * Cout * 16;
     const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
-    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(blocks), dim3(256), 0, st, w_oihw, wp, Cout, Cin, KH, KW, cs, nsteps);
+    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(blocks), dim3(256), 0, st, w_oihw, wp, Cout, Cin, KH, KW, cs, nsteps,
+                       transposed);
     SBGM_LAUNCH_CHECK();
     return 0;
 }
@@ -356,8 +368,15 @@ int sbgm_launch_conv(const ConvGeom& g, ConvParams p, const ConvTile& cfg, float
     SBGM_CHECK(p.proj_w == nullptr || (p.Cout == 16 * cfg.fco && cfg.splits <= 1 && p.proj_out != nullptr),
                "conv: the fused tap projection needs one wave tile over all %d output channels and no grid split-K", p.Cout);
     SBGM_CHECK((size_t)p.B * p.H * p.W * p.Cs * 4 < (1ull << 31), "conv: input tensor exceeds 2 GiB buffer window");
-    p.OH = (p.H + 2 * g.pad - g.kh) / g.stride + 1;
-    p.OW = (p.W + 2 * g.pad - g.kw) / g.stride + 1;
+    if (p.in_dil != 2) p.in_dil = 1;
+    if (p.out_h > 0 && p.out_w > 0) {           // explicit output size (data-gradient of a strided convolution)
+        p.OH = p.out_h;
+        p.OW = p.out_w;
+    } else {
+        SBGM_CHECK(p.in_dil == 1, "conv: a dilated-input (transposed) convolution needs an explicit output size");
+        p.OH = (p.H + 2 * g.pad - g.kh) / g.stride + 1;
+        p.OW = (p.W + 2 * g.pad - g.kw) / g.stride + 1;
+    }
     p.M = p.B * p.OH * p.OW;
     p.cb_per_tap = p.Cs >= 16 ? p.Cs / 16 : 1;
     p.nsteps = sbgm_conv_nsteps(g.kh, g.kw, p.Cs);
@@ -383,6 +402,7 @@ int sbgm_launch_conv(const ConvGeom& g, ConvParams p, const ConvTile& cfg, float
         rc = launch_geom<KH_, KW_, S_, PAD_, CM_>(p, cfg, grid, st);
     SBGM_GEOM(8, 8, 2, 3, 0) SBGM_GEOM(8, 8, 2, 3, 4) SBGM_GEOM(8, 8, 2, 3, 8)
     SBGM_GEOM(3, 3, 1, 1, 0) SBGM_GEOM(3, 3, 2, 1, 0) SBGM_GEOM(1, 1, 2, 0, 0) SBGM_GEOM(1, 1, 1, 0, 0)
+    SBGM_GEOM(8, 8, 1, 4, 0)                       // data-gradient of the 8x8/s2/p3 stem convolution
 #undef SBGM_GEOM
     SBGM_CHECK(rc == 0, "conv: no kernel for k=%dx%d s=%d p=%d cs=%d tile=%dx%d ws=%d", g.kh, g.kw, g.stride, g.pad, p.Cs,
                cfg.fco, cfg.fpx, cfg.ws);

@@ -25,13 +25,17 @@ struct ConvParams {
     int act, tbias_after_act;
     const float* proj_w;  // [9][Cout] or null: fuse the following 3x3 Cout=1 conv's per-tap channel dot products
     float* proj_out;      // [9][M] planar tap sums (then `out` is not written)
+    int in_dil;           // 1, or 2: read the input through a zero-inserted grid (data-gradient of a stride-2 conv)
+    int out_h, out_w;     // explicit output size (required with in_dil == 2), else 0
     // filled by sbgm_launch_conv:
     int OH, OW, M, cb_per_tap, nsteps, steps_per_split, n_px_tiles, n_co_tiles;
     uint32_t x_bytes, w_bytes;
 };
 
 int sbgm_conv_nsteps(int KH, int KW, int cs);
-int sbgm_launch_pack_conv_weight(const float* w_oihw, float* wp, int Cout, int Cin, int KH, int KW, int cs, hipStream_t st);
+// transposed != 0 packs the data-gradient operator (swap Cout/Cin, flip taps); then Cout/Cin are the transposed sizes
+int sbgm_launch_pack_conv_weight(const float* w_oihw, float* wp, int Cout, int Cin, int KH, int KW, int cs, hipStream_t st,
+                                 int transposed = 0);
 int sbgm_launch_conv(const ConvGeom& g, ConvParams p, const ConvTile& cfg, float* partial_ws, hipStream_t st);
 
 // ---- pointwise.hip ---------------------------------------------------------------------------------
@@ -64,6 +68,7 @@ struct TimeEmbedArgs {
     TimeProj proj[16];
     int n_proj;
     float* emb_ws;              // workspace [n_emb][B][D]: silu(embedding)
+    float* emb_raw;             // optional [n_emb][B][D]: embedding before the SiLU (training)
     int B, D;
 };
 int sbgm_launch_time_embed(const TimeEmbedArgs& a, hipStream_t st);
@@ -81,7 +86,7 @@ int sbgm_launch_pack_cout1_weight(const float* w_oihw, float* w_tap_c, int C, hi
 // batchnorm needs 24*C bytes (zeroed by the launcher).
 int sbgm_launch_groupnorm(const float* x, float* y, const float* gamma, const float* beta, const float* skip,
                           const float* tbias, int act, int B, int HW, int C, int G, float eps, double* stats_ws,
-                          hipStream_t st);
+                          hipStream_t st, float* mr_out = nullptr);   // mr_out: [B][G][2] (mean, rstd) kept for backward
 int sbgm_launch_layernorm(const float* x, float* y, const float* gamma, const float* beta, int M, int C, float eps,
                           hipStream_t st);
 // train-mode BatchNorm2d: batch statistics over (B,H,W), running-stat update, optional residual + ReLU
@@ -116,3 +121,26 @@ int sbgm_launch_langevin(float* x, const float* score, const float* z, float snr
                          SamplerState* state, unsigned long long draw_index, unsigned long long seed, int B,
                          size_t per_sample, hipStream_t st);
 int sbgm_launch_cfg_combine(float* out, const float* s_cond, const float* s_uncond, float scale, size_t n, hipStream_t st);
+
+// ---- backward.hip (training path) ------------------------------------------------------------------------------------
+int sbgm_launch_conv_wgrad(const float* dy, const float* x, float* dw_oihw, float* dwp_ws, int B, int H, int W, int Cs, int Cin,
+                           int Cout, int KH, int KW, int S, int PAD, hipStream_t st);
+int sbgm_launch_colsum(const float* x, const float* y, float* out, int M, int C, hipStream_t st);
+int sbgm_launch_samplesum(const float* x, float* out, int B, int HW, int C, hipStream_t st);
+int sbgm_launch_groupnorm_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* skip,
+                              const float* tbias, const float* mr, int act, float* dx, float* dskip, float* dgamma, float* dbeta,
+                              float* dtbias, float* s12_ws, int B, int HW, int C, int G, hipStream_t st);
+int sbgm_launch_batchnorm_bwd(const float* x, const float* dy, const float* y, const float* gamma, const float* tbias_after,
+                              const float* mr, int relu, float* dx, float* dres, float* dgamma, float* dbeta, float* s12_ws, int B,
+                              int HW, int C, hipStream_t st);
+int sbgm_launch_layernorm_bwd(const float* x, const float* dy, const float* gamma, float* dx, float* dgamma, float* dbeta, int M, int C,
+                              float eps, hipStream_t st);
+int sbgm_launch_mha_core_bwd(const float* qkv, const float* dout, float* dqkv, int B, int S, int C, int heads, hipStream_t st);
+int sbgm_launch_upsample2x_bwd(const float* dy, float* dx, int B, int H, int W, int C, hipStream_t st);
+int sbgm_launch_cout1_bwd(const float* dout, const float* a, const float* w_tap_c, const float* t, float sigma, float* da,
+                          float* dw_tap_c, float* dbias, int B, int H, int W, int C, hipStream_t st);
+int sbgm_launch_time_proj_bwd(const float* dout, const float* weight, const float* semb, const float* emb_raw, float* dW, float* dbias,
+                              float* demb_accum, int B, int D, int ch, hipStream_t st);
+int sbgm_launch_label_emb_bwd(const float* demb, const int64_t* y, float* dtable, int B, int D, hipStream_t st);
+int sbgm_launch_act_bwd(const float* x, const float* dy, float* dx, size_t n, int act, hipStream_t st);
+int sbgm_launch_act_fwd(const float* x, float* y, size_t n, int act, hipStream_t st);

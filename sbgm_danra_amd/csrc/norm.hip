@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const float* __res
                                                               const float* __restrict__ skip,
                                                               const float* __restrict__ tbias, int act, int HW, int C,
                                                               int G, int chunks, float eps,
-                                                              const double* __restrict__ stats) {
+                                                              const double* __restrict__ stats, float* __restrict__ mr_out) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* mr = reinterpret_cast<float*>(smem_raw);        // [G][2] mean, rstd
     const int b = blockIdx.y;
@@ -135,6 +135,10 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const float* __res
         const double var = fmax(a2 * inv_n - mean * mean, 0.0);
         mr[2 * g] = (float)mean;
         mr[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+        if (mr_out != nullptr && blockIdx.x == 0) {          // saved for the backward pass
+            mr_out[((size_t)b * G + g) * 2] = mr[2 * g];
+            mr_out[((size_t)b * G + g) * 2 + 1] = mr[2 * g + 1];
+        }
     }
     __syncthreads();
     const size_t per_sample = (size_t)HW * cq;
@@ -239,7 +243,7 @@ inline int stream_blocks(size_t work_items) { return (int)std::min<size_t>((work
 
 int sbgm_launch_groupnorm(const float* x, float* y, const float* gamma, const float* beta, const float* skip,
                           const float* tbias, int act, int B, int HW, int C, int G, float eps, double* stats_ws,
-                          hipStream_t st) {
+                          hipStream_t st, float* mr_out) {
     SBGM_CHECK(C % 4 == 0 && C <= 1024 && C % G == 0, "groupnorm: C=%d G=%d unsupported", C, G);
     SBGM_CHECK((gamma == nullptr) == (beta == nullptr), "groupnorm: gamma and beta must both be set or both null");
     // pass 1: per-(sample, pixel-chunk, group) partial sums, plain stores (no zeroing, no atomics, deterministic);
@@ -254,7 +258,7 @@ int sbgm_launch_groupnorm(const float* x, float* y, const float* gamma, const fl
     const size_t per_sample = (size_t)HW * (C / 4);
     const int bx = (int)std::max<size_t>(1, std::min<size_t>((per_sample + 255) / 256, 2048 / std::max(1, B) + 1));
     hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(bx, B), dim3(256), 2 * G * sizeof(float), st, x, y, gamma, beta, skip, tbias,
-                       act, HW, C, G, chunks, eps, stats_ws);
+                       act, HW, C, G, chunks, eps, stats_ws, mr_out);
     SBGM_LAUNCH_CHECK();
     return 0;
 }

@@ -119,6 +119,7 @@ __global__ __launch_bounds__(256) void time_embed_kernel(TimeEmbedArgs a) {
         const float proj = (a.t[b] * w) * 6.283185307179586f;
         float e = d < half ? sinf(proj) : cosf(proj);
         if (g == 0 && a.y != nullptr) e += a.label_emb[(size_t)a.y[b] * a.D + d];
+        if (a.emb_raw) a.emb_raw[i] = e;                 // kept for the backward pass (SiLU')
         a.emb_ws[i] = e / (1.f + expf(-e));
     }
 }

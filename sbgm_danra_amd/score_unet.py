@@ -272,21 +272,6 @@ class _Engine:
         self.version = tuple((k, v.data_ptr(), v._version) for k, v in sd.items())
 
 
-class _NoBackward(torch.autograd.Function):
-    """Marks the engine output as depending on the parameters so that `.backward()` fails loudly instead of
-    silently producing no gradients (the native training backward is not implemented in this round)."""
-
-    @staticmethod
-    def forward(ctx, out, *params):
-        return out.view_as(out)
-
-    @staticmethod
-    def backward(ctx, *grads):
-        raise NotImplementedError(
-            "backward through the native SBGM engine is not implemented yet (this round ships inference + "
-            "sampling); evaluate under torch.no_grad() or train with the reference implementation")
-
-
 class ScoreNet(nn.Module):
     """encoder -> decoder -> divide by sigma(t), evaluated by the native engine (reference score_unet.py:792-879)."""
 
@@ -330,6 +315,17 @@ class ScoreNet(nn.Module):
                 cond_img: Optional[torch.Tensor] = None, lsm_cond: Optional[torch.Tensor] = None,
                 topo_cond: Optional[torch.Tensor] = None, *, _fmaps: Optional[list] = None):
         x, t, y, cond_img, lsm_cond, topo_cond = self._prep(x, t, y, cond_img, lsm_cond, topo_cond)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            # training: op-by-op graph of native kernels with hand-written backward passes (train_graph.py)
+            if not self.training:
+                raise NotImplementedError("gradients through an eval()-mode (running-statistics BatchNorm) network are not "
+                                          "implemented; call model.train() or evaluate under torch.no_grad()")
+            if _fmaps is not None:
+                raise ValueError("_fmaps is an inference-only debugging hook")
+            from .train_graph import forward_train
+            if 1 + sum(0 if c is None else c.shape[1] for c in (lsm_cond, topo_cond, cond_img)) != self.encoder.input_channels:
+                raise ValueError("input channel mismatch between the conditioning tensors and encoder.conv1")
+            return forward_train(self, x, t, y, cond_img, lsm_cond, topo_cond)
         eng = self._engine(lsm_cond, topo_cond, cond_img)
         B, _, H, W = x.shape
         out = torch.empty_like(x)
@@ -349,10 +345,6 @@ class ScoreNet(nn.Module):
                 s = self.marginal_prob_std(t)
                 logger.info(f"[pre-σ-div] mean = {float(pre.mean()):.4g}, std = {float(pre.std()):.4g}, "
                             f"σ ∈ [{s.min():.4g}, {s.max():.4g}]")
-        if torch.is_grad_enabled():
-            ps = [p for p in self.parameters() if p.requires_grad]
-            if ps:
-                out = _NoBackward.apply(out, *ps)
         return out
 
     def autotune(self, batch: int, height: int, width: int, cond_channels=(0, 0, 1)):
@@ -388,8 +380,8 @@ diffusion_coeff_fn = functools.partial(diffusion_coeff, sigma=sigma)
 def loss_fn(model, x, marginal_prob_std, t_eps=1e-3, device=None, y=None, cond_img=None, lsm_cond=None,
             topo_cond=None, sdf_cond=None):
     """Denoising score-matching loss (reference score_unet.py:936-985): same RNG order (`rand(B)` then
-    `randn_like(x)`), same batch-size checks.  Usable under no_grad (validation); the training backward is not
-    implemented natively yet, so `.backward()` on the result raises NotImplementedError."""
+    `randn_like(x)`), same batch-size checks.  With grad enabled the network runs through train_graph.forward_train
+    (native forward + backward kernels); the few [B,1,H,W]-sized elementwise ops of the loss itself are tensor ops."""
     random_t = torch.rand(x.shape[0], device=x.device) * (1.0 - t_eps) + t_eps
     z = torch.randn_like(x)
     std = marginal_prob_std(random_t)

@@ -1,0 +1,375 @@
+"""Training path: the ScoreNet forward as a graph of native ops with hand-written HIP backward kernels.
+
+Inference and sampling run the whole network inside the C++ engine (`sbgm_model_forward`).  Training needs every
+intermediate for `loss.backward()` (reference training.py:403-405), so here the same launch sequence is issued op by
+op through the per-op C ABI, each op wrapped in a `torch.autograd.Function` whose forward AND backward are HIP
+kernels from libsbgm_hip.so (conv data-gradient = the forward implicit-GEMM kernel on transposed/flipped weights,
+conv weight-gradient = MFMA GEMM over pixels, norm / attention / upsample / time-embedding backward kernels in
+csrc/backward.hip).  PyTorch contributes the autograd tape, tensor storage and `torch.optim`; no torch.nn op is called.
+
+Activations are NHWC fp32 tensors `[B, H, W, C]`; parameters stay in the reference layouts (OIHW etc.) and are
+repacked per step (they change every optimizer step).  Semantics follow the reference in train mode: BatchNorm uses
+batch statistics and updates `running_mean/var/num_batches_tracked` (momentum 0.1, unbiased variance).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _native as N
+
+_L = N.lib
+_ACT = {"ReLU": N.RELU, "SiLU": N.SILU, "GELU": N.GELU, "Identity": N.NONE}
+
+
+def _st():
+    return N.stream()
+
+
+def _pad_c(c):
+    return 4 if c <= 4 else 8 if c <= 8 else (c + 15) // 16 * 16
+
+
+def _conv_launch(x, packed, out, cs, cout, k, stride, pad, bias=None, res=None, tbias=None, in_dil=0, out_hw=(0, 0)):
+    B, H, W, _ = x.shape
+    a = N.ConvArgs(x.data_ptr(), packed.data_ptr(), out.data_ptr(), None, N.ptr(bias), N.ptr(tbias), N.ptr(res), B, H, W, cs, cout, k, k,
+                   stride, pad, N.NONE, 0, 0, 0, 0, 0, in_dil, out_hw[0], out_hw[1], None, 0)
+    N.check(_L().sbgm_conv2d_fwd(C.byref(a), _st()))
+
+
+class ConvFn(torch.autograd.Function):
+    """y = conv2d(x, w, stride, pad) [+ bias] [+ tbias[b] broadcast over pixels] [+ res]   (NHWC x, OIHW w).
+    Also serves nn.Linear as a 1x1 conv."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, res, tbias, stride, pad):
+        B, H, W, cs = x.shape
+        cout, cin, k, _ = w.shape
+        packed = torch.empty(_L().sbgm_conv_packed_numel(cout, k, k, cs), device=x.device)
+        N.check(_L().sbgm_conv_pack_weight(w.data_ptr(), packed.data_ptr(), cout, cin, k, k, cs, _st()))
+        oh, ow = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        y = torch.empty(B, oh, ow, cout, device=x.device)
+        _conv_launch(x, packed, y, cs, cout, k, stride, pad, bias, res, tbias)
+        ctx.save_for_backward(x, w)
+        ctx.geom = (stride, pad, bias is not None, res is not None, tbias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, pad, has_bias, has_res, has_tb = ctx.geom
+        dy = dy.contiguous()
+        B, H, W, cs = x.shape
+        cout, cin, k, _ = w.shape
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            if cs != cin or cs % 32:
+                raise NotImplementedError("data gradient w.r.t. a channel-padded input is not needed on this path")
+            packed = torch.empty(_L().sbgm_conv_packed_numel(cin, k, k, cout), device=x.device)
+            N.check(_L().sbgm_conv_pack_weight_dgrad(w.data_ptr(), packed.data_ptr(), cout, cin, k, k, _st()))
+            dx = torch.empty_like(x)
+            _conv_launch(dy, packed, dx, cout, cin, k, 1, k - 1 - pad, in_dil=2 if stride == 2 else 0, out_hw=(H, W))
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(w)
+            ws = torch.empty(k * k * cout * cs, device=x.device)
+            N.check(_L().sbgm_conv2d_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), ws.data_ptr(), B, H, W, cs, cin, cout, k, k,
+                                           stride, pad, _st()))
+        if has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty(cout, device=x.device)
+            N.check(_L().sbgm_colsum(dy.data_ptr(), None, db.data_ptr(), dy.numel() // cout, cout, _st()))
+        dtb = None
+        if has_tb and ctx.needs_input_grad[4]:
+            dtb = torch.empty(B, cout, device=x.device)
+            N.check(_L().sbgm_samplesum(dy.data_ptr(), dtb.data_ptr(), B, dy.numel() // (B * cout), cout, _st()))
+        return dx, dw, db, (dy if has_res and ctx.needs_input_grad[3] else None), dtb, None, None
+
+
+def linear(x2d, w, b, res=None):
+    """nn.Linear over tokens [M, C] (+ residual) on the conv kernel"""
+    M, Cc = x2d.shape
+    y = ConvFn.apply(x2d.view(1, 1, M, Cc), w.view(w.shape[0], w.shape[1], 1, 1), b,
+                     None if res is None else res.view(1, 1, M, -1), None, 1, 0)
+    return y.view(M, -1)
+
+
+class BNTrainFn(torch.autograd.Function):
+    """y = relu?(BatchNorm_train(x) [+ res]) [+ tbias_after]; updates running statistics in place"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rm, rv, res, tb_after, relu, eps, momentum):
+        B, H, W, Cc = x.shape
+        y = torch.empty_like(x)
+        ws = torch.empty(24 * Cc + 64, dtype=torch.uint8, device=x.device)
+        N.check(_L().sbgm_batchnorm_train_fwd(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(),
+                                              rv.data_ptr(), N.ptr(res), N.ptr(tb_after), int(relu), B, H * W, Cc, eps, momentum,
+                                              ws.data_ptr(), _st()))
+        ctx.save_for_backward(x, y, gamma, tb_after, ws)
+        ctx.cfg = (relu, res is not None, tb_after is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, tb_after, ws = ctx.saved_tensors
+        relu, has_res, has_tb = ctx.cfg
+        dy = dy.contiguous()
+        B, H, W, Cc = x.shape
+        dx, dres = torch.empty_like(x), (torch.empty_like(x) if has_res else None)
+        dg, db = torch.empty(Cc, device=x.device), torch.empty(Cc, device=x.device)
+        s12 = torch.empty(B * Cc * 2, device=x.device)
+        mr = ws.data_ptr() + 16 * Cc                     # [C][2] floats behind the 2C doubles
+        N.check(_L().sbgm_batchnorm_bwd(x.data_ptr(), dy.data_ptr(), y.data_ptr(), gamma.data_ptr(), N.ptr(tb_after), mr, int(relu),
+                                        dx.data_ptr(), N.ptr(dres), dg.data_ptr(), db.data_ptr(), s12.data_ptr(), B, H * W, Cc, _st()))
+        dtb = None
+        if has_tb:
+            dtb = torch.empty(B, Cc, device=x.device)
+            N.check(_L().sbgm_samplesum(dy.data_ptr(), dtb.data_ptr(), B, H * W, Cc, _st()))
+        return dx, dg, db, None, None, dres, dtb, None, None, None
+
+
+class GroupNormFn(torch.autograd.Function):
+    """y = act(GroupNorm(x) [+ skip] [+ tbias])   (gamma/beta None = InstanceNorm2d without affine)"""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, skip, tbias, act, G, eps):
+        B, H, W, Cc = x.shape
+        y = torch.empty_like(x)
+        ws = torch.empty(1024 * B * G, dtype=torch.uint8, device=x.device)
+        mr = torch.empty(B * G * 2, device=x.device)
+        N.check(_L().sbgm_groupnorm_fwd(x.data_ptr(), y.data_ptr(), N.ptr(gamma), N.ptr(beta), N.ptr(skip), N.ptr(tbias), act, B, H * W,
+                                        Cc, G, eps, ws.data_ptr(), mr.data_ptr(), _st()))
+        ctx.save_for_backward(x, gamma, beta, skip, tbias, mr)
+        ctx.cfg = (act, G)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, skip, tbias, mr = ctx.saved_tensors
+        act, G = ctx.cfg
+        dy = dy.contiguous()
+        B, H, W, Cc = x.shape
+        dev = x.device
+        dx = torch.empty_like(x)
+        dskip = torch.empty_like(x) if skip is not None else None
+        dg = torch.empty(Cc, device=dev) if gamma is not None else None
+        db = torch.empty(Cc, device=dev) if gamma is not None else None
+        dtb = torch.empty(B, Cc, device=dev) if tbias is not None else None
+        s12 = torch.empty(B * Cc * 2, device=dev)
+        N.check(_L().sbgm_groupnorm_bwd(x.data_ptr(), dy.data_ptr(), N.ptr(gamma), N.ptr(beta), N.ptr(skip), N.ptr(tbias), mr.data_ptr(),
+                                        act, dx.data_ptr(), N.ptr(dskip), N.ptr(dg), N.ptr(db), N.ptr(dtb), s12.data_ptr(), B, H * W, Cc,
+                                        G, _st()))
+        return dx, dg, db, dskip, dtb, None, None, None
+
+
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        M, Cc = x.shape
+        y = torch.empty_like(x)
+        N.check(_L().sbgm_layernorm_fwd(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), M, Cc, eps, _st()))
+        ctx.save_for_backward(x, gamma)
+        ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma = ctx.saved_tensors
+        dy = dy.contiguous()
+        M, Cc = x.shape
+        dx, dg, db = torch.empty_like(x), torch.empty(Cc, device=x.device), torch.empty(Cc, device=x.device)
+        N.check(_L().sbgm_layernorm_bwd(x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), M, Cc,
+                                        ctx.eps, _st()))
+        return dx, dg, db, None
+
+
+class MHACoreFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, B, S, Cc, heads):
+        out = torch.empty(B * S, Cc, device=qkv.device)
+        N.check(_L().sbgm_mha_core_fwd(qkv.data_ptr(), out.data_ptr(), B, S, Cc, heads, _st()))
+        ctx.save_for_backward(qkv)
+        ctx.dims = (B, S, Cc, heads)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (qkv,) = ctx.saved_tensors
+        B, S, Cc, heads = ctx.dims
+        dout = dout.contiguous()
+        dqkv = torch.empty_like(qkv)
+        N.check(_L().sbgm_mha_core_bwd(qkv.data_ptr(), dout.data_ptr(), dqkv.data_ptr(), B, S, Cc, heads, _st()))
+        return dqkv, None, None, None, None
+
+
+class UpsampleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        B, H, W, Cc = x.shape
+        y = torch.empty(B, 2 * H, 2 * W, Cc, device=x.device)
+        N.check(_L().sbgm_upsample2x_fwd(x.data_ptr(), y.data_ptr(), B, H, W, Cc, _st()))
+        ctx.dims = (B, H, W, Cc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, H, W, Cc = ctx.dims
+        dy = dy.contiguous()
+        dx = torch.empty(B, H, W, Cc, device=dy.device)
+        N.check(_L().sbgm_upsample2x_bwd(dy.data_ptr(), dx.data_ptr(), B, H, W, Cc, _st()))
+        return dx
+
+
+class ActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act):
+        y = torch.empty_like(x)
+        N.check(_L().sbgm_act_fwd(x.data_ptr(), y.data_ptr(), x.numel(), act, _st()))
+        ctx.save_for_backward(x)
+        ctx.act = act
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        N.check(_L().sbgm_act_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), ctx.act, _st()))
+        return dx, None
+
+
+class TimeProjFn(torch.autograd.Function):
+    """SinusoidalEmbedding(t) [+ label_emb(y)] -> SiLU -> Linear : [B] -> [B, ch]"""
+
+    @staticmethod
+    def forward(ctx, t, y, table, freqs, weight, bias):
+        B, (ch, D) = t.numel(), weight.shape
+        out, semb, raw = torch.empty(B, ch, device=t.device), torch.empty(B, D, device=t.device), torch.empty(B, D, device=t.device)
+        N.check(_L().sbgm_time_proj_fwd(t.data_ptr(), N.ptr(y), N.ptr(table) if y is not None else None, freqs.data_ptr(),
+                                        weight.data_ptr(), bias.data_ptr(), out.data_ptr(), semb.data_ptr(), raw.data_ptr(), B, D, ch,
+                                        _st()))
+        ctx.save_for_backward(weight, semb, raw, y if y is not None else torch.empty(0), table if table is not None else torch.empty(0))
+        ctx.has_y = y is not None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        weight, semb, raw, y, table = ctx.saved_tensors
+        dout = dout.contiguous()
+        B, (ch, D) = dout.shape[0], weight.shape
+        dW, db = torch.empty_like(weight), torch.empty(ch, device=dout.device)
+        demb = torch.zeros(B, D, device=dout.device) if ctx.has_y else None
+        N.check(_L().sbgm_time_proj_bwd(dout.data_ptr(), weight.data_ptr(), semb.data_ptr(), raw.data_ptr(), dW.data_ptr(), db.data_ptr(),
+                                        N.ptr(demb), B, D, ch, _st()))
+        dtable = None
+        if ctx.has_y:
+            dtable = torch.zeros_like(table)
+            N.check(_L().sbgm_label_emb_bwd(demb.data_ptr(), y.data_ptr(), dtable.data_ptr(), B, D, _st()))
+        return None, None, dtable, None, dW, db
+
+
+class Cout1Fn(torch.autograd.Function):
+    """final_layer.conv (3x3, C -> 1) followed by the division by sigma(t): NHWC a -> NCHW [B,1,H,W]"""
+
+    @staticmethod
+    def forward(ctx, a, w, bias, t, sigma):
+        B, H, W, Cc = a.shape
+        wp = torch.empty(9 * Cc, device=a.device)
+        N.check(_L().sbgm_cout1_pack_weight(w.data_ptr(), wp.data_ptr(), Cc, _st()))
+        out = torch.empty(B, 1, H, W, device=a.device)
+        N.check(_L().sbgm_conv3x3_cout1_fwd(a.data_ptr(), wp.data_ptr(), bias.data_ptr(), t.data_ptr(), sigma, out.data_ptr(), B, H, W, Cc,
+                                            _st()))
+        ctx.save_for_backward(a, wp, t)
+        ctx.sigma = sigma
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        a, wp, t = ctx.saved_tensors
+        dout = dout.contiguous()
+        B, H, W, Cc = a.shape
+        da, dwp, db = torch.empty_like(a), torch.empty(9 * Cc, device=a.device), torch.empty(1, device=a.device)
+        N.check(_L().sbgm_conv3x3_cout1_bwd(dout.data_ptr(), a.data_ptr(), wp.data_ptr(), t.data_ptr(), ctx.sigma, da.data_ptr(),
+                                            dwp.data_ptr(), db.data_ptr(), B, H, W, Cc, _st()))
+        dw = dwp.view(3, 3, Cc).permute(2, 0, 1).reshape(1, Cc, 3, 3).contiguous()      # [tap][c] -> OIHW
+        return da, dw, db, None, None
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# the network (train mode), same order as Encoder.forward / DecoderBlock.forward / Decoder.forward of the reference
+# ----------------------------------------------------------------------------------------------------------------------
+def _pack_inputs(x, lsm, topo, cond, cs):
+    srcs = [s for s in (x, lsm, topo, cond) if s is not None]
+    B, _, H, W = x.shape
+    out = torch.empty(B, H, W, cs, device=x.device)
+    ptrs = (C.c_void_p * len(srcs))(*[s.data_ptr() for s in srcs])
+    chs = (C.c_int * len(srcs))(*[s.shape[1] for s in srcs])
+    N.check(_L().sbgm_pack_input(ptrs, chs, len(srcs), out.data_ptr(), B, H, W, cs, _st()))
+    return out
+
+
+def _bn(x, bn, res=None, tb_after=None, relu=True):
+    y = BNTrainFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, res, tb_after, relu, bn.eps, bn.momentum)
+    with torch.no_grad():
+        bn.num_batches_tracked += 1
+    return y
+
+
+def _attention(mod, x):                               # x: [B, H, W, C] -> same (reference score_unet.py:136-148)
+    B, H, W, Cc = x.shape
+    tok = x.reshape(B * H * W, Cc)
+    n1 = LayerNormFn.apply(tok, mod.ln1.weight, mod.ln1.bias, mod.ln1.eps)
+    qkv = linear(n1, mod.mha.in_proj_weight, mod.mha.in_proj_bias)
+    att = MHACoreFn.apply(qkv, B, H * W, Cc, mod.n_heads)
+    h = linear(att, mod.mha.out_proj.weight, mod.mha.out_proj.bias, res=tok)
+    n2 = LayerNormFn.apply(h, mod.ln2.weight, mod.ln2.bias, mod.ln2.eps)
+    f = ActFn.apply(linear(n2, mod.ff[0].weight, mod.ff[0].bias), N.GELU)
+    return linear(f, mod.ff[2].weight, mod.ff[2].bias, res=h).view(B, H, W, Cc)
+
+
+def forward_train(net, x, t, y, cond, lsm, topo):
+    enc, dec = net.encoder, net.decoder
+    if not dec.use_resize_conv:
+        raise NotImplementedError("model.use_resize_conv=false is not implemented natively")
+    sigma = float(net.sigma)
+    tlabel = enc.label_emb.weight if (y is not None and enc.num_classes is not None) else None
+    if y is not None and tlabel is None:
+        raise ValueError("y given but the model has no label embedding")
+
+    def tproj(freq_mod, seq, with_label):
+        return TimeProjFn.apply(t, y if with_label else None, tlabel if with_label else None, freq_mod.W, seq[1].weight, seq[1].bias)
+
+    x0 = _pack_inputs(x, lsm, topo, cond, _pad_c(enc.input_channels))
+    tb = [tproj(enc.sinusoidal_embedding, enc.time_projection_layers[i], y is not None) for i in range(5)]
+    f1 = ConvFn.apply(x0, enc.conv1.weight, None, None, tb[0], 2, 3)                    # conv1 + time bias (:312-316)
+    h = _bn(ConvFn.apply(f1, enc.conv2.weight, None, None, None, 2, 3), enc.bn1)
+    fmaps = [f1]
+    for li in range(1, 5):
+        layer = getattr(enc, f"layer{li}")
+        for bi, blk in enumerate(layer):
+            y1 = _bn(ConvFn.apply(h, blk.conv1.weight, None, None, None, blk.stride, 1), blk.bn1)
+            idn = h
+            if blk.downsample is not None:
+                idn = _bn(ConvFn.apply(h, blk.downsample[0].weight, None, None, None, blk.stride, 0), blk.downsample[1], relu=False)
+            last = bi == len(layer) - 1
+            h = _bn(ConvFn.apply(y1, blk.conv2.weight, None, None, None, 1, 1), blk.bn2, res=idn, tb_after=tb[li] if last else None)
+        if not isinstance(enc.attention_layers[li], torch.nn.Identity):
+            h = _attention(enc.attention_layers[li], h)
+        fmaps.append(h)
+
+    act = _ACT.get(dec.activation.__name__)
+    cur = fmaps[4]
+    for i, blk in enumerate(dec.residual_layers):
+        group = dec.norm == "group"
+        G1 = max(1, min(dec.gn_groups, blk.input_channels)) if group else blk.input_channels
+        G2 = max(1, min(dec.gn_groups, blk.output_channels)) if group else blk.output_channels
+        g = lambda n: (n.weight, n.bias) if group else (None, None)   # noqa: E731
+        a = ConvFn.apply(UpsampleFn.apply(cur), blk.conv_up.weight, blk.conv_up.bias, None, None, 1, 1)
+        a = GroupNormFn.apply(a, *g(blk.norm1), None, None, N.NONE, G1, 1e-5)
+        c2 = ConvFn.apply(a, blk.conv.weight, blk.conv.bias, None, None, 1, 1)
+        tbd = tproj(blk.sinusoidal_embedding, blk.time_projection_layer, False)
+        cur = GroupNormFn.apply(c2, *g(blk.norm2), fmaps[3 - i], tbd, act, G2, 1e-5)
+        if blk.compute_attn:
+            cur = _attention(blk.attention, cur)
+    fin = dec.final_layer
+    a = ConvFn.apply(UpsampleFn.apply(cur), fin.conv_up.weight, fin.conv_up.bias, None, None, 1, 1)
+    return Cout1Fn.apply(a, fin.conv.weight, fin.conv.bias, t, sigma)

@@ -1,0 +1,267 @@
+"""Training path on the GPU: every native backward kernel against PyTorch-CPU autograd of the same op, then the whole
+loss_fn gradient against the golden vectors captured from the reference (tests/golden/loss_b2_64.npz) and a two-step
+Adam trajectory against the CPU oracle.  Tolerance: 1e-4 max-rel on gradients (fp32 atomics reorder sums)."""
+import math
+import os
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from sbgm_danra_amd import _native as N  # noqa: E402
+from sbgm_danra_amd import train_graph as T  # noqa: E402
+from util_models import build_pair, load_golden, maxrel  # noqa: E402
+
+GT = 1e-4
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return torch.randn(*shape, generator=g) * scale
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def leaf(t, dev=False):
+    t = t.clone().cuda() if dev else t.clone()
+    return t.requires_grad_(True)
+
+
+@pytest.mark.parametrize("B,Cin,H,Cout,k,s,p", [(2, 64, 8, 64, 3, 1, 1), (2, 64, 8, 128, 3, 2, 1), (2, 64, 8, 128, 1, 2, 0),
+                                                 (1, 64, 16, 64, 8, 2, 3), (2, 128, 4, 64, 3, 1, 1), (1, 256, 2, 512, 3, 2, 1)])
+def test_conv_backward(B, Cin, H, Cout, k, s, p):
+    x, w, b = rnd(B, Cin, H, H), rnd(Cout, Cin, k, k, seed=1, scale=1 / math.sqrt(Cin * k * k)), rnd(Cout, seed=2)
+    res_shape = F.conv2d(x, w, b, s, p).shape
+    res, tb, go = rnd(*res_shape, seed=3), rnd(B, Cout, seed=4), rnd(*res_shape, seed=5)
+    xr, wr, br, rr, tr = leaf(x), leaf(w), leaf(b), leaf(res), leaf(tb)
+    (F.conv2d(xr, wr, br, s, p) + rr + tr[:, :, None, None]).backward(go)
+    xd, wd, bd, rd, td = leaf(nhwc(x), True), leaf(w, True), leaf(b, True), leaf(nhwc(res), True), leaf(tb, True)
+    y = T.ConvFn.apply(xd, wd, bd, rd, td, s, p)
+    y.backward(nhwc(go).cuda())
+    assert maxrel(nchw(xd.grad.cpu()), xr.grad) < GT
+    assert maxrel(wd.grad.cpu(), wr.grad) < GT and maxrel(bd.grad.cpu(), br.grad) < GT
+    assert maxrel(nchw(rd.grad.cpu()), rr.grad) < GT and maxrel(td.grad.cpu(), tr.grad) < GT
+
+
+@pytest.mark.parametrize("cin", [2, 7, 13])
+def test_stem_conv_weight_gradient_with_padded_channels(cin):
+    B, H = 2, 32
+    x, w, go = rnd(B, cin, H, H), rnd(64, cin, 8, 8, seed=1, scale=0.05), rnd(B, 64, H // 2, H // 2, seed=2)
+    wr = leaf(w)
+    F.conv2d(x, wr, None, 2, 3).backward(go)
+    cs = T._pad_c(cin)
+    xp = torch.zeros(B, H, H, cs)
+    xp[..., :cin] = nhwc(x)
+    wd = leaf(w, True)
+    T.ConvFn.apply(xp.cuda(), wd, None, None, None, 2, 3).backward(nhwc(go).cuda())
+    assert maxrel(wd.grad.cpu(), wr.grad) < GT
+
+
+@pytest.mark.parametrize("with_res", [False, True])
+def test_batchnorm_train_backward(with_res):
+    B, Cc, H = 3, 64, 6
+    x, g, b = rnd(B, Cc, H, H) * 2 + 0.3, rnd(Cc, seed=1), rnd(Cc, seed=2)
+    res, tb, go = rnd(B, Cc, H, H, seed=3), rnd(B, Cc, seed=4), rnd(B, Cc, H, H, seed=5)
+    xr, gr, br, rr, tr = leaf(x), leaf(g), leaf(b), leaf(res), leaf(tb)
+    y = F.batch_norm(xr, torch.zeros(Cc), torch.ones(Cc), gr, br, True, 0.1, 1e-5)
+    y = (F.relu(y + rr) + tr[:, :, None, None]) if with_res else F.relu(y)
+    y.backward(go)
+    xd, gd, bd = leaf(nhwc(x), True), leaf(g, True), leaf(b, True)
+    rd, td = (leaf(nhwc(res), True), leaf(tb, True)) if with_res else (None, None)
+    yd = T.BNTrainFn.apply(xd, gd, bd, torch.zeros(Cc).cuda(), torch.ones(Cc).cuda(), rd, td, True, 1e-5, 0.1)
+    assert maxrel(nchw(yd.detach().cpu()), y.detach()) < 1e-5
+    yd.backward(nhwc(go).cuda())
+    assert maxrel(nchw(xd.grad.cpu()), xr.grad) < GT and maxrel(gd.grad.cpu(), gr.grad) < GT and maxrel(bd.grad.cpu(), br.grad) < GT
+    if with_res:
+        assert maxrel(nchw(rd.grad.cpu()), rr.grad) < GT and maxrel(td.grad.cpu(), tr.grad) < GT
+
+
+@pytest.mark.parametrize("Cc,G,act", [(64, 8, N.SILU), (128, 8, N.NONE), (64, 64, N.RELU), (256, 8, N.GELU)])
+def test_groupnorm_backward(Cc, G, act):
+    B, H = 2, 8
+    affine = G != Cc
+    x, go = rnd(B, Cc, H, H) * 1.5 + 0.2, rnd(B, Cc, H, H, seed=5)
+    g, b = (rnd(Cc, seed=1), rnd(Cc, seed=2)) if affine else (None, None)
+    skip, tb = rnd(B, Cc, H, H, seed=3), rnd(B, Cc, seed=4)
+    fn = {N.SILU: F.silu, N.RELU: F.relu, N.GELU: F.gelu, N.NONE: lambda v: v}[act]
+    xr, sr, tr = leaf(x), leaf(skip), leaf(tb)
+    gr, br = (leaf(g), leaf(b)) if affine else (None, None)
+    fn(F.group_norm(xr, G, gr, br, 1e-5) + sr + tr[:, :, None, None]).backward(go)
+    xd, sd, td = leaf(nhwc(x), True), leaf(nhwc(skip), True), leaf(tb, True)
+    gd, bd = (leaf(g, True), leaf(b, True)) if affine else (None, None)
+    T.GroupNormFn.apply(xd, gd, bd, sd, td, act, G, 1e-5).backward(nhwc(go).cuda())
+    assert maxrel(nchw(xd.grad.cpu()), xr.grad) < GT and maxrel(nchw(sd.grad.cpu()), sr.grad) < GT and maxrel(td.grad.cpu(), tr.grad) < GT
+    if affine:
+        assert maxrel(gd.grad.cpu(), gr.grad) < GT and maxrel(bd.grad.cpu(), br.grad) < GT
+
+
+def test_layernorm_act_upsample_backward():
+    M, Cc = 40, 256
+    x, g, b, go = rnd(M, Cc) * 2 + 1, rnd(Cc, seed=1), rnd(Cc, seed=2), rnd(M, Cc, seed=3)
+    xr, gr, br = leaf(x), leaf(g), leaf(b)
+    F.layer_norm(xr, (Cc,), gr, br, 1e-5).backward(go)
+    xd, gd, bd = leaf(x, True), leaf(g, True), leaf(b, True)
+    T.LayerNormFn.apply(xd, gd, bd, 1e-5).backward(go.cuda())
+    assert maxrel(xd.grad.cpu(), xr.grad) < GT and maxrel(gd.grad.cpu(), gr.grad) < GT and maxrel(bd.grad.cpu(), br.grad) < GT
+    xr = leaf(x)
+    F.gelu(xr).backward(go)
+    xd = leaf(x, True)
+    T.ActFn.apply(xd, N.GELU).backward(go.cuda())
+    assert maxrel(xd.grad.cpu(), xr.grad) < 1e-5
+    for shape in [(2, 64, 4, 4), (1, 64, 1, 1), (1, 128, 3, 5)]:
+        u = rnd(*shape)
+        gu = rnd(shape[0], shape[1], 2 * shape[2], 2 * shape[3], seed=7)
+        ur = leaf(u)
+        F.interpolate(ur, scale_factor=2, mode="bilinear", align_corners=False).backward(gu)
+        ud = leaf(nhwc(u), True)
+        T.UpsampleFn.apply(ud).backward(nhwc(gu).cuda())
+        assert maxrel(nchw(ud.grad.cpu()), ur.grad) < 1e-5
+
+
+@pytest.mark.parametrize("B,S,Cc,heads", [(2, 64, 256, 4), (1, 16, 512, 4), (1, 256, 128, 4), (2, 4, 256, 2)])
+def test_mha_core_backward(B, S, Cc, heads):
+    qkv, go = rnd(B * S, 3 * Cc), rnd(B * S, Cc, seed=1)
+    d = Cc // heads
+    qr = leaf(qkv)
+    q, k, v = [t.view(B, S, heads, d).transpose(1, 2) for t in qr.view(B, S, 3 * Cc).split(Cc, dim=-1)]
+    att = torch.softmax((q / math.sqrt(d)) @ k.transpose(-1, -2), -1) @ v
+    att.transpose(1, 2).reshape(B * S, Cc).backward(go)
+    qd = leaf(qkv, True)
+    T.MHACoreFn.apply(qd, B, S, Cc, heads).backward(go.cuda())
+    assert maxrel(qd.grad.cpu(), qr.grad) < GT
+
+
+@pytest.mark.parametrize("with_y", [False, True])
+def test_time_projection_backward(with_y):
+    B, D, ch = 4, 256, 128
+    t = torch.tensor([1e-3, 0.2, 0.7, 1.0])
+    freqs, w, b, table, go = rnd(D // 2) * 30, rnd(ch, D, seed=1) * 0.05, rnd(ch, seed=2), rnd(5, D, seed=3), rnd(B, ch, seed=4)
+    y = torch.tensor([1, 4, 0, 2]) if with_y else None
+    wr, br, tabr = leaf(w), leaf(b), leaf(table)
+    pr = t[:, None] * freqs[None, :] * (2 * torch.pi)
+    emb = torch.cat([pr.sin(), pr.cos()], -1)
+    if with_y:
+        emb = emb + tabr[y]
+    F.linear(F.silu(emb), wr, br).backward(go)
+    wd, bd, tabd = leaf(w, True), leaf(b, True), leaf(table, True)
+    T.TimeProjFn.apply(t.cuda(), y.cuda() if with_y else None, tabd if with_y else None, freqs.cuda(), wd, bd).backward(go.cuda())
+    assert maxrel(wd.grad.cpu(), wr.grad) < GT and maxrel(bd.grad.cpu(), br.grad) < GT
+    if with_y:
+        assert maxrel(tabd.grad.cpu(), tabr.grad) < GT
+
+
+def test_final_conv_backward():
+    B, Cc, H, W = 2, 64, 10, 12
+    a, w, b, t, go = rnd(B, Cc, H, W), rnd(1, Cc, 3, 3, seed=1) * 0.05, rnd(1, seed=2), torch.tensor([0.05, 0.8]), rnd(B, 1, H, W, seed=3)
+    ar, wr, br = leaf(a), leaf(w), leaf(b)
+    ls = math.log(25.0)
+    std = torch.sqrt((torch.exp(2 * t * ls) - 1) / (2 * ls))
+    (F.conv2d(ar, wr, br, 1, 1) / std.view(-1, 1, 1, 1)).backward(go)
+    ad, wd, bd = leaf(nhwc(a), True), leaf(w, True), leaf(b, True)
+    T.Cout1Fn.apply(ad, wd, bd, t.cuda(), 25.0).backward(go.cuda())
+    assert maxrel(nchw(ad.grad.cpu()), ar.grad) < GT and maxrel(wd.grad.cpu(), wr.grad) < GT and maxrel(bd.grad.cpu(), br.grad) < GT
+
+
+def test_loss_gradients_match_reference_goldens(golden_dir):
+    """loss value + gradients of the 7 probe parameters recorded from the reference's loss_fn + backward"""
+    import sbgm_danra_amd as S
+    g = load_golden(os.path.join(golden_dir, "loss_b2_64.npz"))
+    _, net, _ = build_pair(1)
+    net.train()
+    x, cond, sdf, t, z = (g[k].cuda() for k in ("x", "cond_img", "sdf", "t", "z"))
+    std = S.marginal_prob_std_fn(t)
+    score = net(x + std[:, None, None, None] * z, t, cond_img=cond)
+    wgt = torch.sigmoid(sdf) * 0.5 + 0.5
+    loss = torch.mean(torch.sum(wgt * (score * std[:, None, None, None] + z) ** 2, dim=(1, 2, 3)))
+    loss.backward()
+    assert abs(float(loss) / float(g["loss"]) - 1) < 1e-5
+    params = dict(net.named_parameters())
+    for k in [k for k in g if k.startswith("grad::")]:
+        gr = params[k[6:]].grad.reshape(-1).cpu()
+        assert maxrel(gr[:: max(1, gr.numel() // 2048)][:2048], g[k]) < 2e-4, k
+
+
+def _batch(gen, B=3, hw=64):
+    x, cond = torch.randn(B, 1, hw, hw, generator=gen), torch.randn(B, 1, hw, hw, generator=gen)
+    lsm = torch.cat([(torch.rand(B, 1, hw, hw, generator=gen) > 0.5).float(), torch.ones(B, 1, hw, hw)], 1)
+    topo = torch.cat([torch.rand(B, 1, hw, hw, generator=gen), torch.ones(B, 1, hw, hw)], 1)
+    y = torch.randint(0, 5, (B,), generator=gen)
+    t, z = torch.rand(B, generator=gen) * 0.999 + 1e-3, torch.randn(B, 1, hw, hw, generator=gen)
+    return x, cond, lsm, topo, y, t, z
+
+
+def _native_loss(net, S, x, cond, lsm, topo, y, t, z):
+    std = S.marginal_prob_std_fn(t.cuda())
+    sc = net(x.cuda() + std[:, None, None, None] * z.cuda(), t.cuda(), y.cuda(), cond.cuda(), lsm.cuda(), topo.cuda())
+    return torch.mean(torch.sum((sc * std[:, None, None, None] + z.cuda()) ** 2, dim=(1, 2, 3)))
+
+
+def test_every_parameter_gradient_matches_the_oracle():
+    """7-channel input, seasons, geo conditions: all 166 parameter gradients vs CPU autograd of the oracle"""
+    import sbgm_danra_amd as S
+    from oracle import torch_ref as O
+    ora, net, _ = build_pair(5, 4)
+    ora.train(), net.train()
+    x, cond, lsm, topo, y, t, z = _batch(torch.Generator().manual_seed(11))
+    lo = O.loss_fn(ora, x, O.marginal_prob_std_fn, y=y, cond_img=cond, lsm_cond=lsm, topo_cond=topo, noise=(t, z))
+    lo.backward()
+    ln = _native_loss(net, S, x, cond, lsm, topo, y, t, z)
+    ln.backward()
+    assert abs(float(ln.detach()) / float(lo.detach()) - 1) < 1e-5
+    po, pn = dict(ora.named_parameters()), dict(net.named_parameters())
+    unused = ("decoder.final_layer.time_projection_layer", "decoder.final_layer.sinusoidal")
+    errs = {}
+    for k, p in po.items():
+        if k.startswith(unused):
+            assert pn[k].grad is None and p.grad is None          # never used by the forward (score_unet.py:757)
+            continue
+        errs[k] = maxrel(pn[k].grad.cpu(), p.grad)
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    assert worst[0][1] < 5e-4, worst
+    # BatchNorm running statistics moved identically
+    so, sn = ora.state_dict(), net.state_dict()
+    for k in so:
+        if "running_" in k:
+            assert maxrel(sn[k].cpu(), so[k]) < 1e-4, k
+        if k.endswith("num_batches_tracked"):
+            assert int(sn[k]) == int(so[k])
+
+
+def test_two_sgd_steps_track_the_oracle():
+    """same data and injected (t, z): parameters after 2 SGD steps agree with the CPU oracle; the inference engine then
+    sees the updated weights (version-counter re-upload)"""
+    import sbgm_danra_amd as S
+    from oracle import torch_ref as O
+    ora, net, _ = build_pair(5, 4)
+    ora.train(), net.train()
+    opt_o, opt_n = torch.optim.SGD(ora.parameters(), lr=1e-3), torch.optim.SGD(net.parameters(), lr=1e-3)
+    gen = torch.Generator().manual_seed(12)
+    for _ in range(2):
+        b = _batch(gen, B=2)
+        x, cond, lsm, topo, y, t, z = b
+        opt_o.zero_grad()
+        lo = O.loss_fn(ora, x, O.marginal_prob_std_fn, y=y, cond_img=cond, lsm_cond=lsm, topo_cond=topo, noise=(t, z))
+        lo.backward()
+        opt_o.step()
+        opt_n.zero_grad()
+        ln = _native_loss(net, S, *b)
+        ln.backward()
+        opt_n.step()
+        assert abs(float(ln.detach()) / float(lo.detach()) - 1) < 1e-4
+    so, sn = ora.state_dict(), net.state_dict()
+    worst = max(maxrel(sn[k].cpu().float(), so[k].float()) for k in so if so[k].dtype.is_floating_point)
+    assert worst < 1e-3, worst            # the second step amplifies the first step's ~1e-5 gradient noise
+    ora.eval(), net.eval()
+    x, cond, lsm, topo, y, t, z = _batch(gen, B=2)
+    with torch.no_grad():
+        want = ora(x, t, y, cond, lsm, topo)
+        got = net(x.cuda(), t.cuda(), y.cuda(), cond.cuda(), lsm.cuda(), topo.cuda()).cpu()
+    assert maxrel(got, want) < 1e-4

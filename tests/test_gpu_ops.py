@@ -56,7 +56,7 @@ def run_conv(x, w, stride, pad, scale=None, bias=None, tbias=None, res=None, rel
     ws = torch.empty(max(1, splits) * out.numel(), device=DEV)
     a = N.ConvArgs(xd.data_ptr(), packed.data_ptr(), out.data_ptr(), N.ptr(sc), N.ptr(bi), N.ptr(tb), N.ptr(rs), B, H, W, cp,
                    Cout, KH, KW, stride, pad, N.GELU if gelu else (N.RELU if relu else N.NONE), int(after), tile[0], tile[1], splits, wpt,
-                   ws.data_ptr(), ws.numel())
+                   0, 0, 0, ws.data_ptr(), ws.numel())
     N.check(lib().sbgm_conv2d_fwd(C.byref(a), N.stream()))
     torch.cuda.synchronize()
     return nchw(out.cpu())
@@ -189,7 +189,7 @@ def test_groupnorm(C_, G, hw, full):
     dv = lambda t: None if t is None else t.contiguous().to(DEV)  # noqa: E731
     g_, b_, s_, t_ = dv(gamma), dv(beta), dv(None if skip is None else nhwc(skip)), dv(tb)
     N.check(lib().sbgm_groupnorm_fwd(xd.data_ptr(), y.data_ptr(), N.ptr(g_), N.ptr(b_), N.ptr(s_), N.ptr(t_),
-                                     N.SILU if full else N.NONE, B, H * W, C_, G, 1e-5, ws.data_ptr(), N.stream()))
+                                     N.SILU if full else N.NONE, B, H * W, C_, G, 1e-5, ws.data_ptr(), None, N.stream()))
     want = F.group_norm(x, G, gamma, beta, 1e-5)
     if full:
         want = F.silu(want + skip + tb[:, :, None, None])
@@ -274,7 +274,7 @@ def test_time_projection(with_y):
     yd = None if y is None else y.to(DEV)
     out, ws = torch.empty(B, ch, device=DEV), torch.empty(B * D, device=DEV)
     N.check(lib().sbgm_time_proj_fwd(td.data_ptr(), N.ptr(yd), tabd.data_ptr() if with_y else None, fd.data_ptr(), wd.data_ptr(),
-                                     bd.data_ptr(), out.data_ptr(), ws.data_ptr(), B, D, ch, N.stream()))
+                                     bd.data_ptr(), out.data_ptr(), ws.data_ptr(), None, B, D, ch, N.stream()))
     assert relerr(out.cpu(), want) < 2e-5
 
 

@@ -77,3 +77,22 @@ def test_pipeline_validation_and_checkpoint_roundtrip(cfg_path):
     assert set(ck) == {"network_params", "optimizer_params"}
     gen = pipe.generate_and_plot_samples(gen_dl, cfg=cfg, epoch=1)
     assert gen.shape[1:] == (1, 64, 64) and torch.isfinite(gen).all()
+
+
+def test_cli_train_one_epoch_then_generate(cfg_path):
+    """`--mode full_pipeline` end to end on synthetic batches: native forward+backward, Adam, best-val checkpoint in the
+    reference's format, then generation from that checkpoint."""
+    from sbgm.cli import main_app
+    from sbgm.utils import get_model_string, load_config
+    cfg = load_config(cfg_path)
+    main_app.main(["--config_path", cfg_path, "--mode", "full_pipeline", "--skip_evaluation"])
+    ckpt = os.path.join(cfg.paths.path_save, cfg.paths.checkpoint_dir, get_model_string(cfg) + ".pth.tar")
+    # checkpoint_dir is absolute in this config, so path_save/checkpoint_dir == checkpoint_dir
+    assert os.path.exists(ckpt)
+    ck = torch.load(ckpt, weights_only=True)
+    assert set(ck) == {"network_params", "optimizer_params"} and len(ck["network_params"]) == 232
+    assert all(torch.isfinite(v).all() for v in ck["network_params"].values() if v.dtype.is_floating_point)
+    out = os.path.join(cfg.paths.sample_dir, "generation", get_model_string(cfg), "generated_samples")
+    assert np.isfinite(np.load(os.path.join(out, "gen_samples_multi_n_3.npz"))["arr_0"]).all()
+    losses = os.path.join(cfg.paths.path_save, "samples", get_model_string(cfg), "losses", f"losses_{get_model_string(cfg)}.pkl")
+    assert os.path.exists(losses)
