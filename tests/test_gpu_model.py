@@ -169,18 +169,20 @@ def test_errors_are_loud():
     from sbgm_danra_amd._native import NativeError
     _, net, _ = build_pair(1)
     net.eval()
-    with pytest.raises(NativeError):
-        net(torch.randn(1, 1, 32, 32), torch.rand(1), cond_img=torch.randn(1, 1, 32, 32))        # CPU tensors: no fallback
-    with pytest.raises(ValueError):
-        net(torch.randn(2, 1, 32, 32).cuda(), torch.rand(2).cuda(), cond_img=torch.randn(2, 1, 32, 32).cuda(),
-            lsm_cond=torch.randn(3, 2, 32, 32).cuda())                                             # batch mismatch (reference :275)
-    with pytest.raises(ValueError):
-        net(torch.randn(2, 1, 32, 32).cuda(), torch.rand(2).cuda())                               # missing cond channels
-    with pytest.raises(NativeError):
-        with torch.no_grad():
+    with torch.no_grad():
+        with pytest.raises(NativeError):
+            net(torch.randn(1, 1, 32, 32), torch.rand(1), cond_img=torch.randn(1, 1, 32, 32))        # CPU tensors: no fallback
+        with pytest.raises(ValueError):
+            net(torch.randn(2, 1, 32, 32).cuda(), torch.rand(2).cuda(), cond_img=torch.randn(2, 1, 32, 32).cuda(),
+                lsm_cond=torch.randn(3, 2, 32, 32).cuda())                                             # batch mismatch (reference :275)
+        with pytest.raises(ValueError):
+            net(torch.randn(2, 1, 32, 32).cuda(), torch.rand(2).cuda())                               # missing cond channels
+        with pytest.raises(NativeError):
             net(torch.randn(1, 1, 40, 40).cuda(), torch.rand(1).cuda(), cond_img=torch.randn(1, 1, 40, 40).cuda())   # not /32
+    with pytest.raises(NotImplementedError):          # gradients through eval-mode BatchNorm are not implemented: say so
+        net(torch.randn(1, 1, 32, 32).cuda(), torch.rand(1).cuda(), cond_img=torch.randn(1, 1, 32, 32).cuda())
     net.train()
     loss = S.loss_fn(net, torch.randn(2, 1, 32, 32).cuda(), S.marginal_prob_std_fn, cond_img=torch.randn(2, 1, 32, 32).cuda())
-    assert torch.isfinite(loss)
-    with pytest.raises(NotImplementedError):
-        loss.backward()                                                                            # no silent zero gradients
+    loss.backward()
+    assert torch.isfinite(loss) and all(p.grad is not None and torch.isfinite(p.grad).all()
+                                        for k, p in net.named_parameters() if not k.startswith("decoder.final_layer.time_"))
