@@ -266,4 +266,4 @@ def test_two_sgd_steps_track_the_oracle():
     with torch.no_grad():
         want = ora(x, t, y, cond, lsm, topo)
         got = net(x.cuda(), t.cuda(), y.cuda(), cond.cuda(), lsm.cuda(), topo.cuda()).cpu()
-    assert maxrel(got, want) < 1e-4
+    assert maxrel(got, want) < 1e-3         # the two models' weights now differ by up to ~5e-4 (above)
