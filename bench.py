@@ -87,6 +87,60 @@ def cpu_baseline(batch, hw, budget_s=20.0):
                       f"({dt:.1f} s, PyTorch-CPU {torch.__version__}, {model})"}
 
 
+def train_bench(a):
+    """BASELINE configs[2]: 128x128, 4 ERA5 conditions -> 1 target, batch 8 per GPU (global 64 on 8), one optimizer step =
+    loss_fn forward + native backward + RCCL gradient all-reduce (world > 1) + Adam.  Secondary line: not the headline."""
+    import torch.distributed as dist
+    import sbgm_danra_amd as S
+    from sbgm_danra_amd import parallel
+    rank, world, local = parallel.init_distributed()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    net = build_model(dev, n_cond=4)
+    net.train()
+    parallel.broadcast_parameters(net)
+    opt = torch.optim.Adam(net.parameters(), lr=5e-4, weight_decay=1e-6)
+    bucket = parallel.GradientBucket(net.parameters()) if world > 1 else None
+    B, HW = (a.batch if a.batch != 32 else 8), a.size
+    g = torch.Generator().manual_seed(42 + rank)
+    x, cond = torch.randn(B, 1, HW, HW, generator=g).to(dev), torch.randn(B, 4, HW, HW, generator=g).to(dev)
+
+    def step():
+        opt.zero_grad()
+        loss = S.loss_fn(net, x, S.marginal_prob_std_fn, cond_img=cond)
+        loss.backward()
+        if bucket is not None:
+            bucket.all_reduce_()
+        opt.step()
+        return loss
+
+    for _ in range(max(1, a.warmup)):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    if rank == 0:
+        print(json.dumps({"metric": "training samples/sec at 128x128 (forward + backward + Adam)", "value": B * world * a.steps / dt,
+                          "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": f"{HW}x{HW} 4-cond->1-target (C_in=5), batch {B}/GPU, loss_fn + backward + Adam"
+                                                 + (", RCCL gradient all-reduce (76 MB bucket)" if world > 1 else ""),
+                                     "global_batch": B * world, "final_loss": float(loss.detach())}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -99,7 +153,11 @@ def main():
     ap.add_argument("--no-autotune", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--profile-csv", default=None, help="write the per-convolution event timings here")
+    ap.add_argument("--mode", choices=["sample", "train"], default="sample",
+                    help="sample = BASELINE configs[1] (the headline metric); train = configs[2] optimizer steps (secondary line)")
     a = ap.parse_args()
+    if a.mode == "train":
+        return train_bench(a)
 
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
