@@ -149,12 +149,17 @@ typedef struct sbgm_conv_args {
     int tile_co, tile_px;    /* wave tile in 16-element fragments: {2,4} x {1,2,4}; 0 = default */
     int splits;              /* split-K over the grid (needs ws); 0/1 = off */
     int waves_per_tile;      /* in-workgroup split-K: 1, 2 or 4 waves share one tile; 0 = 1 */
+    int winograd;            /* 1: 3x3/s1/p1 through the Winograd F(2,3) kernel; w_packed from sbgm_conv_wino_pack_weight,
+                                tile_px then counts 32-pixel (16-pair) fragments: {4,1} {2,2} {2,1} {4,2} */
     int in_dil;              /* 0/1, or 2: read x through a zero-inserted grid (data gradient of a stride-2 conv) */
     int out_h, out_w;        /* explicit output size (required with in_dil = 2), else 0 */
     float* ws;
     int64_t ws_floats;
 } sbgm_conv_args;
 int sbgm_conv2d_fwd(const sbgm_conv_args* a, void* stream);
+/* Winograd F(2,3)-along-rows weight transform for 3x3 kernels: OIHW -> U[kh][c/16][xi][Cout][16] */
+int64_t sbgm_conv_wino_packed_numel(int Cout, int c_pad);
+int sbgm_conv_wino_pack_weight(const float* w_oihw, float* packed, int Cout, int Cin, int c_pad, void* stream);
 
 /* nn.Upsample(scale_factor=2, mode="bilinear", align_corners=False).  score_unet.py:467 */
 int sbgm_upsample2x_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream);

@@ -42,7 +42,7 @@ class ConvArgs(C.Structure):
     _fields_ = [("x", _vp), ("w_packed", _vp), ("out", _vp), ("scale", _vp), ("bias", _vp), ("tbias", _vp),
                 ("residual", _vp), ("B", _i), ("H", _i), ("W", _i), ("c_pad", _i), ("Cout", _i), ("KH", _i), ("KW", _i),
                 ("stride", _i), ("pad", _i), ("act", _i), ("tbias_after_act", _i), ("tile_co", _i), ("tile_px", _i),
-                ("splits", _i), ("waves_per_tile", _i), ("in_dil", _i), ("out_h", _i), ("out_w", _i), ("ws", _vp),
+                ("splits", _i), ("waves_per_tile", _i), ("winograd", _i), ("in_dil", _i), ("out_h", _i), ("out_w", _i), ("ws", _vp),
                 ("ws_floats", _i64)]
 
 
@@ -72,6 +72,8 @@ SIGNATURES = {
     "sbgm_conv_packed_numel": (_i64, [_i, _i, _i, _i]),
     "sbgm_conv_pack_weight": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sbgm_conv2d_fwd": (_i, [C.POINTER(ConvArgs), _vp]),
+    "sbgm_conv_wino_packed_numel": (_i64, [_i, _i]),
+    "sbgm_conv_wino_pack_weight": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "sbgm_upsample2x_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "sbgm_groupnorm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "sbgm_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),

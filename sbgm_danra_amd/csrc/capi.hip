@@ -25,6 +25,10 @@ int sbgm_nhwc_to_nchw(const float* src, float* dst, int B, int H, int W, int C, 
 int64_t sbgm_conv_packed_numel(int Cout, int KH, int KW, int c_pad) {
     return (int64_t)sbgm_conv_nsteps(KH, KW, c_pad) * Cout * 16;
 }
+int64_t sbgm_conv_wino_packed_numel(int Cout, int c_pad) { return (int64_t)sbgm_wino_packed_floats(Cout, c_pad); }
+int sbgm_conv_wino_pack_weight(const float* w_oihw, float* packed, int Cout, int Cin, int c_pad, void* stream) {
+    return sbgm_launch_pack_wino_weight(w_oihw, packed, Cout, Cin, c_pad, ST);
+}
 int sbgm_conv_pack_weight(const float* w_oihw, float* packed, int Cout, int Cin, int KH, int KW, int c_pad, void* stream) {
     return sbgm_launch_pack_conv_weight(w_oihw, packed, Cout, Cin, KH, KW, c_pad, ST);
 }
@@ -39,7 +43,12 @@ int sbgm_conv2d_fwd(const sbgm_conv_args* a, void* stream) {
     p.tbias_after_act = a->tbias_after_act;
     p.in_dil = a->in_dil; p.out_h = a->out_h; p.out_w = a->out_w;
     ConvTile t{a->tile_co ? a->tile_co : (a->Cout % 64 == 0 ? 4 : 2), a->tile_px ? a->tile_px : 2, a->splits ? a->splits : 1,
-               a->waves_per_tile ? a->waves_per_tile : 1};
+               a->waves_per_tile ? a->waves_per_tile : 1, a->winograd};
+    if (a->winograd) {
+        SBGM_CHECK(a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad == 1 && a->in_dil <= 1, "conv2d: Winograd path is 3x3 stride 1 pad 1 only");
+        if (!a->tile_px) t.fpx = 1;
+        return sbgm_launch_conv_wino(p, t, ST);
+    }
     SBGM_CHECK(a->Cout % 32 == 0, "conv2d: Cout=%d must be a multiple of 32", a->Cout);
     if (t.splits > 1) {
         const int OH = a->out_h > 0 ? a->out_h : (a->H + 2 * a->pad - a->KH) / a->stride + 1;

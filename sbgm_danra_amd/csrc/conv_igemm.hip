@@ -21,6 +21,7 @@
 // splitk_reduce_epilogue.
 #include "common.h"
 #include "kernels.h"
+#include "conv_common.h"
 
 namespace {
 
@@ -34,28 +35,6 @@ struct PixLane {      // per-lane decode of the output pixel this lane gathers f
     int base;         // b * H * W  (input pixel index of (b,0,0)); negative => lane inactive
     int y0, x0;       // oy*S - PAD, ox*S - PAD
 };
-
-__device__ __noinline__ f32x4 gelu4(f32x4 v) {      // rare (attention FF only): keep the erf expansion out of line
-#pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = sbgm_act(v[e], SBGM_ACT_GELU);
-    return v;
-}
-
-// scale/bias (folded BN or conv bias) -> early time bias -> residual -> activation -> late time bias
-__device__ __forceinline__ f32x4 conv_epilogue(f32x4 v, const ConvParams& p, int co, size_t m, int b) {
-    if (p.scale) v *= *reinterpret_cast<const f32x4*>(p.scale + co);
-    if (p.bias) v += *reinterpret_cast<const f32x4*>(p.bias + co);
-    if (p.tbias && !p.tbias_after_act) v += *reinterpret_cast<const f32x4*>(p.tbias + (size_t)b * p.Cout + co);
-    if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + m * p.Cout + co);
-    if (p.act == SBGM_ACT_RELU) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-    } else if (p.act == SBGM_ACT_GELU) {
-        v = gelu4(v);
-    }
-    if (p.tbias && p.tbias_after_act) v += *reinterpret_cast<const f32x4*>(p.tbias + (size_t)b * p.Cout + co);
-    return v;
-}
 
 template <int KH, int KW, int S, int PAD, int FCO, int FPX, int CMODE, int WS>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {

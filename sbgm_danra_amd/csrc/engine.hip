@@ -5,6 +5,7 @@
 // sbgm/score_sampling.py:63-127 / :136-230.
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <map>
@@ -33,6 +34,9 @@ struct Param {
     int cout = 0, cin = 0, kh = 1, kw = 1, cs = 0;   // P_CONV geometry (cs = padded Cin)
     float* dev = nullptr;       // engine storage (packed for P_CONV / P_COUT1)
     size_t dev_floats = 0;
+    bool wino = false;          // 3x3 stride-1 conv: keep a Winograd F(2,3) packed copy as well
+    float* dev_wino = nullptr;
+    size_t wino_floats = 0;
     bool filled = false;
 };
 
@@ -99,10 +103,11 @@ struct sbgm_model {
         return p;
     }
     Param* vec(const std::string& n, int64_t numel) { return add(n, P_VEC, numel); }
-    Param* convw(const std::string& n, int cout, int cin, int kh, int kw, int cs = 0) {
+    Param* convw(const std::string& n, int cout, int cin, int kh, int kw, int cs = 0, bool wino = false) {
         Param* p = add(n, P_CONV, (int64_t)cout * cin * kh * kw);
         p->cout = cout; p->cin = cin; p->kh = kh; p->kw = kw;
         p->cs = cs ? cs : (int)align_up(cin, 16);
+        p->wino = wino && kh == 3 && kw == 3 && p->cs % 16 == 0 && getenv("SBGM_NO_WINOGRAD") == nullptr;
         return p;
     }
     BNW bn(const std::string& pre, int c) {
@@ -149,6 +154,11 @@ struct sbgm_model {
     int fold_bn(hipStream_t st);
     ConvTile pick_tile(const ConvGeom& g, const ConvParams& p);
     int conv(const ConvGeom& g, ConvParams p, hipStream_t st);
+    int launch_any(const ConvGeom& g, ConvParams p, const ConvTile& ct, hipStream_t st) {
+        if (!ct.wino) return sbgm_launch_conv(g, p, ct, partial, st);
+        p.wp = p.wp_wino;
+        return sbgm_launch_conv_wino(p, ct, st);
+    }
     int attention(const AttnW& a, float* x, int B, int S, hipStream_t st);
     int forward(const float* x, const float* t, const int64_t* y, const float* cond, const float* lsm, const float* topo,
                 float* out, float* const* fmaps_out, int B, int H, int W, int bn_train, hipStream_t st);
@@ -176,9 +186,9 @@ int sbgm_model::build(const sbgm_model_config& c) {
             const std::string pre = "encoder.layer" + std::to_string(li + 1) + "." + std::to_string(bi);
             BlockW b;
             b.cin = cin; b.cout = w; b.stride = (bi == 0 && li > 0) ? 2 : 1;
-            b.c1.w = convw(pre + ".conv1.weight", w, cin, 3, 3);
+            b.c1.w = convw(pre + ".conv1.weight", w, cin, 3, 3, 0, b.stride == 1);
             b.bn1 = bn(pre + ".bn1", w);
-            b.c2.w = convw(pre + ".conv2.weight", w, w, 3, 3);
+            b.c2.w = convw(pre + ".conv2.weight", w, w, 3, 3, 0, true);
             b.bn2 = bn(pre + ".bn2", w);
             b.has_ds = (bi == 0) && (b.stride != 1 || cin != w);
             if (b.has_ds) {
@@ -207,7 +217,7 @@ int sbgm_model::build(const sbgm_model_config& c) {
     int dc = c.last_fmap_channels;
     auto dec_block = [&](const std::string& pre, DecW& d, int ci, int co, bool with_norm, bool with_attn) {
         d.cin = ci; d.cout = co; d.has_attn = with_attn;
-        d.up.w = convw(pre + ".conv_up.weight", ci, ci, 3, 3);
+        d.up.w = convw(pre + ".conv_up.weight", ci, ci, 3, 3, 0, true);
         d.up.b = vec(pre + ".conv_up.bias", ci);
         const bool affine = with_norm && c.decoder_norm == SBGM_NORM_GROUP;
         d.n1g = affine ? vec(pre + ".norm1.weight", ci) : nullptr;
@@ -216,7 +226,7 @@ int sbgm_model::build(const sbgm_model_config& c) {
             d.conv.w = add(pre + ".conv.weight", P_COUT1, (int64_t)ci * 9);
             d.conv.w->cin = ci;
         } else {
-            d.conv.w = convw(pre + ".conv.weight", co, ci, 3, 3);
+            d.conv.w = convw(pre + ".conv.weight", co, ci, 3, 3, 0, true);
         }
         d.conv.b = vec(pre + ".conv.bias", co);
         d.n2g = affine ? vec(pre + ".norm2.weight", co) : nullptr;
@@ -248,7 +258,8 @@ int sbgm_model::build(const sbgm_model_config& c) {
         if (p->kind == P_CONV) p->dev_floats = (size_t)sbgm_conv_nsteps(p->kh, p->kw, p->cs) * p->cout * 16;
         else if (p->kind == P_IGNORE) p->dev_floats = 0;
         else p->dev_floats = (size_t)p->numel;
-        total += align_up(p->dev_floats, 64);
+        if (p->wino) p->wino_floats = sbgm_wino_packed_floats(p->cout, p->cs);
+        total += align_up(p->dev_floats, 64) + align_up(p->wino_floats, 64);
     }
     // folded BN scale/bias
     size_t bn_floats = 0;
@@ -263,6 +274,7 @@ int sbgm_model::build(const sbgm_model_config& c) {
     for (auto& up : params) {
         Param* p = up.get();
         if (p->dev_floats) { p->dev = arena + off; off += align_up(p->dev_floats, 64); }
+        if (p->wino_floats) { p->dev_wino = arena + off; off += align_up(p->wino_floats, 64); }
         if (p->kind == P_IGNORE) p->filled = true;
     }
     auto place_bn = [&](BNW& b, int c_) {
@@ -314,7 +326,15 @@ ConvTile sbgm_model::pick_tile(const ConvGeom& g, const ConvParams& p) {
     ConvOpKey key{g.kh, g.kw, g.stride, g.pad, p.B, p.H, p.W, p.Cs, p.Cout, p.proj_w != nullptr};
     auto it = tuned.find(key);
     if (it != tuned.end()) return it->second;
-    if (p.proj_w) return ConvTile{p.Cout / 16, 2, 1, 1};
+    const bool wino_ok = p.wp_wino != nullptr && g.kh == 3 && g.kw == 3 && g.stride == 1 && g.pad == 1 && p.W % 2 == 0;
+    if (wino_ok) {                                    // Winograd F(2,3): 1.5x fewer MFMAs; pick waves-per-tile to fill the chip
+        const int Mp = p.B * OH * OW / 2, ns = 3 * (p.Cs / 16);
+        if (p.proj_w) return ConvTile{p.Cout / 16, 1, 1, 1, 1};
+        const long tiles = (long)((Mp + 31) / 32) * (p.Cout / 32);          // (2,2) tiles: 32 channels x 64 pixels
+        const int ws = tiles >= 2048 ? 1 : (tiles >= 1024 || ns < 8) ? 2 : 4;
+        return ConvTile{2, 2, 1, ws, 1};
+    }
+    if (p.proj_w) return ConvTile{p.Cout / 16, 2, 1, 1, 0};
     const int M = p.B * OH * OW;
     const int nsteps = sbgm_conv_nsteps(g.kh, g.kw, p.Cs);
     const int target = 2048;                 // ~2 waves per SIMD
@@ -323,14 +343,14 @@ ConvTile sbgm_model::pick_tile(const ConvGeom& g, const ConvParams& p) {
         if (p.Cout % (16 * c[0])) continue;
         const long tiles = (long)((M + 16 * c[1] - 1) / (16 * c[1])) * (p.Cout / (16 * c[0]));
         for (int ws : {1, 2, 4})
-            if (tiles * ws >= target && nsteps / ws >= 2) return ConvTile{c[0], c[1], 1, ws};
+            if (tiles * ws >= target && nsteps / ws >= 2) return ConvTile{c[0], c[1], 1, ws, 0};
     }
     // tiny problem: 64x32 (or 32x32) tiles, 4 waves per tile, plus split-K over the grid (>= 2 K-steps per wave)
     const int fco = p.Cout % 64 == 0 ? 4 : 2, fpx = 2;
     const long tiles = (long)((M + 16 * fpx - 1) / (16 * fpx)) * (p.Cout / (16 * fco));
     const int ws = nsteps >= 8 ? 4 : nsteps >= 4 ? 2 : 1;
     const int splits = (int)std::min<long>(std::max<long>(1, target / std::max<long>(1, tiles * ws)), std::max(1, nsteps / (2 * ws)));
-    return ConvTile{fco, fpx, splits, ws};
+    return ConvTile{fco, fpx, splits, ws, 0};
 }
 
 int sbgm_model::conv(const ConvGeom& g, ConvParams p, hipStream_t st) {
@@ -351,7 +371,19 @@ int sbgm_model::conv(const ConvGeom& g, ConvParams p, hipStream_t st) {
                     if (ws > 1 && (nsteps / ws < 2 || ntile * ws > 32768)) continue;
                     for (int sp : {1, 2, 4, 8, 16}) {
                         if (sp > 1 && (p.proj_w || nsteps / (sp * ws) < 2 || ntile * ws >= 4096)) continue;   // already enough waves
-                        cands.push_back(ConvTile{t[0], t[1], sp, ws});
+                        cands.push_back(ConvTile{t[0], t[1], sp, ws, 0});
+                    }
+                }
+            }
+            if (p.wp_wino != nullptr && g.kh == 3 && g.kw == 3 && g.stride == 1 && g.pad == 1 && p.W % 2 == 0) {
+                const int wt[4][2] = {{4, 1}, {2, 2}, {2, 1}, {4, 2}};
+                const int nsw = 3 * (p.Cs / 16);
+                for (auto& t : wt) {
+                    if (p.Cout % (16 * t[0])) continue;
+                    if (p.proj_w && 16 * t[0] != p.Cout) continue;
+                    for (int ws : {1, 2, 4}) {
+                        if (ws > 1 && nsw / ws < 2) continue;
+                        cands.push_back(ConvTile{t[0], t[1], 1, ws, 1});
                     }
                 }
             }
@@ -364,7 +396,7 @@ int sbgm_model::conv(const ConvGeom& g, ConvParams p, hipStream_t st) {
                 if (ct.splits > 1 && mc * ct.splits > PARTIAL_FLOATS) continue;
                 for (int rep = 0; rep < 4; ++rep) {
                     if (rep == 1) SBGM_HIP(hipEventRecord(e0, st));
-                    if (sbgm_launch_conv(g, p, ct, partial, st)) return 1;
+                    if (launch_any(g, p, ct, st)) return 1;
                 }
                 SBGM_HIP(hipEventRecord(e1, st));
                 SBGM_HIP(hipEventSynchronize(e1));
@@ -379,7 +411,7 @@ int sbgm_model::conv(const ConvGeom& g, ConvParams p, hipStream_t st) {
     }
     ConvTile ct = pick_tile(g, p);
     if (ct.splits > 1 && mc * ct.splits > PARTIAL_FLOATS) ct.splits = (int)std::max<size_t>(1, PARTIAL_FLOATS / mc);
-    if (!prof) return sbgm_launch_conv(g, p, ct, partial, st);
+    if (!prof) return launch_any(g, p, ct, st);
     ConvRec r{g, p.B, p.H, p.W, p.Cs, p.Cout, p.B * OH * OW, sbgm_conv_nsteps(g.kh, g.kw, p.Cs), ct, 0.0, nullptr, nullptr, 0.f};
     // algorithmic FLOPs: 2 * M * Cout * (KH*KW*Cin_real); Cs may be padded (only the stem conv), count real K there
     const int cin_real = (g.kh == 8 && p.Cs <= 16) ? cin_total : p.Cs;
@@ -387,7 +419,7 @@ int sbgm_model::conv(const ConvGeom& g, ConvParams p, hipStream_t st) {
     SBGM_HIP(hipEventCreate(&r.e0));
     SBGM_HIP(hipEventCreate(&r.e1));
     SBGM_HIP(hipEventRecord(r.e0, st));
-    const int rc = sbgm_launch_conv(g, p, ct, partial, st);
+    const int rc = launch_any(g, p, ct, st);
     SBGM_HIP(hipEventRecord(r.e1, st));
     prof->push_back(r);
     return rc;
@@ -480,7 +512,7 @@ int sbgm_model::forward(const float* x, const float* t, const int64_t* y, const 
     auto conv_bn = [&](const ConvGeom& g, const float* in, int h, int w, int cs, const ConvW& cw, BNW& bnw, int cout,
                        const float* res, bool relu, const float* tb_after, float* o) -> int {
         ConvParams p{};
-        p.x = in; p.wp = cw.w->dev; p.B = B; p.H = h; p.W = w; p.Cs = cs; p.Cout = cout;
+        p.x = in; p.wp = cw.w->dev; p.wp_wino = cw.w->dev_wino; p.B = B; p.H = h; p.W = w; p.Cs = cs; p.Cout = cout;
         if (!bn_train) {
             p.out = o; p.scale = bnw.scale; p.bias = bnw.bias; p.res = res; p.act = relu ? SBGM_ACT_RELU : SBGM_ACT_NONE;
             p.tbias = tb_after; p.tbias_after_act = 1;
@@ -555,13 +587,13 @@ int sbgm_model::forward(const float* x, const float* t, const int64_t* y, const 
         float* a = wsalloc((size_t)B * oh * ow * d.cin);
         if (!a) return 1;
         ConvParams p{};
-        p.x = up; p.wp = d.up.w->dev; p.out = a; p.bias = d.up.b->dev; p.B = B; p.H = oh; p.W = ow; p.Cs = d.cin; p.Cout = d.cin;
+        p.x = up; p.wp = d.up.w->dev; p.wp_wino = d.up.w->dev_wino; p.out = a; p.bias = d.up.b->dev; p.B = B; p.H = oh; p.W = ow; p.Cs = d.cin; p.Cout = d.cin;
         if (conv(ConvGeom{3, 3, 1, 1}, p, st)) return 1;
         if (sbgm_launch_groupnorm(a, a, d.n1g ? d.n1g->dev : nullptr, d.n1b ? d.n1b->dev : nullptr, nullptr, nullptr,
                                   SBGM_ACT_NONE, B, oh * ow, d.cin, groups(d.cin), GN_EPS, stats, st)) return 1;
         float* c2 = wsalloc((size_t)B * oh * ow * d.cout);
         if (!c2) return 1;
-        p.x = a; p.wp = d.conv.w->dev; p.out = c2; p.bias = d.conv.b->dev; p.Cout = d.cout;
+        p.x = a; p.wp = d.conv.w->dev; p.wp_wino = d.conv.w->dev_wino; p.out = c2; p.bias = d.conv.b->dev; p.Cout = d.cout;
         if (conv(ConvGeom{3, 3, 1, 1}, p, st)) return 1;
         if (sbgm_launch_groupnorm(c2, c2, d.n2g ? d.n2g->dev : nullptr, d.n2b ? d.n2b->dev : nullptr, fm[3 - i], tb[5 + i],
                                   cfg.decoder_activation, B, oh * ow, d.cout, groups(d.cout), GN_EPS, stats, st)) return 1;
@@ -574,7 +606,7 @@ int sbgm_model::forward(const float* x, const float* t, const int64_t* y, const 
         if (!up) return 1;
         if (sbgm_launch_upsample2x(cur, up, B, ch, cw_, ci, st)) return 1;
         ConvParams p{};
-        p.x = up; p.wp = fin_up.w->dev; p.bias = fin_up.b->dev; p.B = B; p.H = H; p.W = W; p.Cs = ci; p.Cout = ci;
+        p.x = up; p.wp = fin_up.w->dev; p.wp_wino = fin_up.w->dev_wino; p.bias = fin_up.b->dev; p.B = B; p.H = H; p.W = W; p.Cs = ci; p.Cout = ci;
         if (ci == 64) {
             // conv_up's 64-channel output feeds only the linear 3x3 Cout=1 conv: project onto its 9 taps in the epilogue
             // (9 floats per pixel instead of 64) and finish with a 9-point gather.
@@ -761,6 +793,7 @@ int sbgm_model_set_param(sbgm_model* m, const char* name, const void* data, int6
         SBGM_HIP(hipMemcpyAsync(p->dev, src, (size_t)numel * 4, hipMemcpyDeviceToDevice, st));
     } else if (p->kind == P_CONV) {
         if (sbgm_launch_pack_conv_weight(src, p->dev, p->cout, p->cin, p->kh, p->kw, p->cs, st)) return 1;
+        if (p->wino && sbgm_launch_pack_wino_weight(src, p->dev_wino, p->cout, p->cin, p->cs, st)) return 1;
     } else {
         if (sbgm_launch_pack_cout1_weight(src, p->dev, p->cin, st)) return 1;
     }
@@ -851,7 +884,7 @@ int sbgm_model_profile_forward(sbgm_model* m, const float* x, const float* t, co
         s.n_conv += 1;
         if (r.ms > s.ms_conv_max) { s.ms_conv_max = r.ms; s.flops_conv_max = r.flops; }
         if (f) fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%.4f,%.4f,%.2f\n", i, r.g.kh, r.g.kw, r.g.stride, r.B, r.H, r.W,
-                       r.Cs, r.Cout, r.M, r.nsteps, 16 * r.t.fco, 16 * r.t.fpx, r.t.splits, r.t.ws, r.flops * 1e-9, r.ms,
+                       r.Cs, r.Cout, r.M, r.nsteps, 16 * r.t.fco, (r.t.wino ? 32 : 16) * r.t.fpx, r.t.splits, r.t.wino ? -r.t.ws : r.t.ws, r.flops * 1e-9, r.ms,
                        r.flops / (r.ms * 1e-3) * 1e-12);
         ++i;
     }

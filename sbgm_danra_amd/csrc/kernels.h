@@ -12,6 +12,7 @@ struct ConvTile {
     int fco, fpx;   // wave tile = (16*fco) output channels x (16*fpx) pixels
     int splits;     // split-K over gridDim.y (partials + reduce kernel)
     int ws;         // waves of a workgroup cooperating on one tile (in-workgroup split-K through LDS): 1, 2 or 4
+    int wino;       // 1 = 3x3/s1 Winograd F(2,3) kernel (conv_wino.hip): fpx then counts PAIR fragments, weights = wino pack
 };
 struct ConvParams {
     const float* x;       // NHWC [B][H][W][Cs]
@@ -25,6 +26,7 @@ struct ConvParams {
     int act, tbias_after_act;
     const float* proj_w;  // [9][Cout] or null: fuse the following 3x3 Cout=1 conv's per-tap channel dot products
     float* proj_out;      // [9][M] planar tap sums (then `out` is not written)
+    const float* wp_wino; // host-side only: Winograd-packed copy of the weights (3x3 stride-1 layers), or null
     int in_dil;           // 1, or 2: read the input through a zero-inserted grid (data-gradient of a stride-2 conv)
     int out_h, out_w;     // explicit output size (required with in_dil == 2), else 0
     // filled by sbgm_launch_conv:
@@ -37,6 +39,11 @@ int sbgm_conv_nsteps(int KH, int KW, int cs);
 int sbgm_launch_pack_conv_weight(const float* w_oihw, float* wp, int Cout, int Cin, int KH, int KW, int cs, hipStream_t st,
                                  int transposed = 0);
 int sbgm_launch_conv(const ConvGeom& g, ConvParams p, const ConvTile& cfg, float* partial_ws, hipStream_t st);
+
+// ---- conv_wino.hip: 3x3 stride-1 pad-1 convolution, 1-D Winograd F(2,3) along rows ------------------------------------
+size_t sbgm_wino_packed_floats(int Cout, int cs);
+int sbgm_launch_pack_wino_weight(const float* w_oihw, float* up, int Cout, int Cin, int cs, hipStream_t st);
+int sbgm_launch_conv_wino(ConvParams p, const ConvTile& cfg, hipStream_t st);   // p.wp = Winograd-packed weights
 
 // ---- pointwise.hip ---------------------------------------------------------------------------------
 struct PackSrc {

@@ -34,7 +34,7 @@ def _pad_c(c):
 def _conv_launch(x, packed, out, cs, cout, k, stride, pad, bias=None, res=None, tbias=None, in_dil=0, out_hw=(0, 0)):
     B, H, W, _ = x.shape
     a = N.ConvArgs(x.data_ptr(), packed.data_ptr(), out.data_ptr(), None, N.ptr(bias), N.ptr(tbias), N.ptr(res), B, H, W, cs, cout, k, k,
-                   stride, pad, N.NONE, 0, 0, 0, 0, 0, in_dil, out_hw[0], out_hw[1], None, 0)
+                   stride, pad, N.NONE, 0, 0, 0, 0, 0, 0, in_dil, out_hw[0], out_hw[1], None, 0)
     N.check(_L().sbgm_conv2d_fwd(C.byref(a), _st()))
 
 

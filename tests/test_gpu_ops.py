@@ -56,7 +56,7 @@ def run_conv(x, w, stride, pad, scale=None, bias=None, tbias=None, res=None, rel
     ws = torch.empty(max(1, splits) * out.numel(), device=DEV)
     a = N.ConvArgs(xd.data_ptr(), packed.data_ptr(), out.data_ptr(), N.ptr(sc), N.ptr(bi), N.ptr(tb), N.ptr(rs), B, H, W, cp,
                    Cout, KH, KW, stride, pad, N.GELU if gelu else (N.RELU if relu else N.NONE), int(after), tile[0], tile[1], splits, wpt,
-                   0, 0, 0, ws.data_ptr(), ws.numel())
+                   0, 0, 0, 0, ws.data_ptr(), ws.numel())
     N.check(lib().sbgm_conv2d_fwd(C.byref(a), N.stream()))
     torch.cuda.synchronize()
     return nchw(out.cpu())
@@ -121,6 +121,44 @@ def test_conv_gelu_epilogue_and_combined_splits():
     for kw in (dict(), dict(wpt=4), dict(wpt=2, splits=2), dict(splits=4)):
         got = run_conv(x, w, 1, 0, bias=b, gelu=True, tile=(4, 2), **kw)
         assert relerr(got, want) < 2e-5, kw
+
+
+def run_wino(x, w, tile, wpt, scale=None, bias=None, tbias=None, res=None, relu=False, after=False):
+    B, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    cp = pad_c(Cin)
+    xp = torch.zeros(B, H, W, cp)
+    xp[..., :Cin] = nhwc(x)
+    xd, wd = xp.to(DEV), w.contiguous().to(DEV)
+    packed = torch.empty(lib().sbgm_conv_wino_packed_numel(Cout, cp), device=DEV)
+    N.check(lib().sbgm_conv_wino_pack_weight(wd.data_ptr(), packed.data_ptr(), Cout, Cin, cp, N.stream()))
+    out = torch.empty(B, H, W, Cout, device=DEV)
+    dv = lambda t: None if t is None else t.contiguous().to(DEV)  # noqa: E731
+    sc, bi, tb, rs = dv(scale), dv(bias), dv(tbias), dv(None if res is None else nhwc(res))
+    a = N.ConvArgs(xd.data_ptr(), packed.data_ptr(), out.data_ptr(), N.ptr(sc), N.ptr(bi), N.ptr(tb), N.ptr(rs), B, H, W, cp, Cout, 3, 3, 1, 1,
+                   N.RELU if relu else N.NONE, int(after), tile[0], tile[1], 0, wpt, 1, 0, 0, 0, None, 0)
+    N.check(lib().sbgm_conv2d_fwd(C.byref(a), N.stream()))
+    torch.cuda.synchronize()
+    return nchw(out.cpu())
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 8, 8, 64), (1, 64, 16, 32, 64), (2, 128, 4, 4, 128), (1, 512, 4, 4, 256), (3, 64, 2, 2, 64),
+                                   (1, 16, 6, 10, 64)])
+@pytest.mark.parametrize("tile", [(4, 1), (2, 2), (2, 1), (4, 2)])
+@pytest.mark.parametrize("wpt", [1, 2, 4])
+def test_conv_winograd_f23(shape, tile, wpt):
+    B, Cin, H, W, Cout = shape
+    x, w = rnd(B, Cin, H, W), rnd(Cout, Cin, 3, 3, seed=1, scale=1.0 / math.sqrt(Cin * 9))
+    got = run_wino(x, w, tile, wpt)
+    assert relerr(got, ref_conv(x, w, 1, 1)) < 2e-5
+
+
+def test_conv_winograd_epilogue():
+    B, Cin, H, W, Cout = 2, 64, 8, 12, 64
+    x, w = rnd(B, Cin, H, W), rnd(Cout, Cin, 3, 3, seed=2, scale=0.04)
+    kw = dict(scale=rnd(Cout, seed=3).abs() + 0.5, bias=rnd(Cout, seed=4), tbias=rnd(B, Cout, seed=5), res=rnd(B, Cout, H, W, seed=6),
+              relu=True, after=True)
+    assert relerr(run_wino(x, w, (4, 1), 2, **kw), ref_conv(x, w, 1, 1, **kw)) < 2e-5
 
 
 @pytest.mark.parametrize("splits", [2, 3, 4, 9])
