@@ -149,8 +149,9 @@ typedef struct sbgm_conv_args {
     int tile_co, tile_px;    /* wave tile in 16-element fragments: {2,4} x {1,2,4}; 0 = default */
     int splits;              /* split-K over the grid (needs ws); 0/1 = off */
     int waves_per_tile;      /* in-workgroup split-K: 1, 2 or 4 waves share one tile; 0 = 1 */
-    int winograd;            /* 1: 3x3/s1/p1 through the Winograd F(2,3) kernel; w_packed from sbgm_conv_wino_pack_weight,
-                                tile_px then counts 32-pixel (16-pair) fragments: {4,1} {2,2} {2,1} {4,2} */
+    int winograd;            /* bit 0: Winograd F(2,3) weights/kernel (3x3/s1/p1; w_packed from sbgm_conv_wino_pack_weight;
+                                tile_px counts 32-pixel fragments: {4,1} {2,2} {2,1} {4,2});
+                                bit 1: LDS-staged kernel (W %% 16 == 0; tile_px = tile rows per wave, 2x that with bit 0) */
     int in_dil;              /* 0/1, or 2: read x through a zero-inserted grid (data gradient of a stride-2 conv) */
     int out_h, out_w;        /* explicit output size (required with in_dil = 2), else 0 */
     float* ws;

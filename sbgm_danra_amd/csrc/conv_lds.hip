@@ -1,0 +1,261 @@
+// 3x3 / stride 1 / pad 1 convolution with LDS-staged input halo patch and weight slab (fp32 MFMA 16x16x4).
+//
+// The wave-level kernel (conv_igemm.hip) re-fetches every input pixel 9x (once per tap) and every weight fragment once
+// per wave; measurements show it is bound by that operand traffic, not by the matrix pipe.  Here a workgroup owns a
+// (4*FPX) x 16 pixel tile of ONE image and 16*FCO output channels.  Per 16-input-channel stage it loads, cooperatively
+// and exactly once,
+//     the halo patch   [(4*FPX+2) x 18 pixels][16 ch]      (NHWC quads, hardware bounds check = zero padding)
+//     the weight slab  [9 taps][16*FCO channels][16 ch]    (1 KiB-contiguous fragments of the packed weights)
+// into LDS, then every wave sweeps the 9 taps out of LDS: A fragments (weights) and B fragments (pixels of a tile row
+// shifted by the tap) are 16-byte ds_read_b128 per lane, 4*FCO*FPX MFMAs per tap.  Global traffic per output drops ~4.5x.
+// Occupancy (2-3 workgroups per CU) overlaps one workgroup's staging with another's MFMAs; one barrier pair per stage.
+// With WINO the 3 kw taps of a filter row are replaced by the 4 products of Winograd F(2,3) (see conv_wino.hip): the
+// patch is read as 4 input columns per output PAIR, transformed in registers, and the slab holds U = G g (12 "taps").
+#include "common.h"
+#include "kernels.h"
+#include "conv_common.h"
+
+namespace {
+
+constexpr int TW = 16;          // tile width = one MFMA fragment of pixels
+constexpr int PWID = TW + 2;    // patch width
+
+template <int FCO, int FPX, bool WINO>
+__global__ __launch_bounds__(256) void conv3x3_lds_kernel(const ConvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int TH = (WINO ? 8 : 4) * FPX;    // tile rows: 4 waves x FPX rows (Winograd: 2*FPX rows per wave)
+    constexpr int PH = TH + 2;
+    constexpr int NCO = 16 * FCO;
+    constexpr int NTAP = WINO ? 12 : 9;
+    constexpr int WQ = NTAP * NCO * 4;          // weight quads (16 B) per stage
+    constexpr int PQ = PH * PWID * 4;           // patch quads per stage
+    f32x4* wl = reinterpret_cast<f32x4*>(smem_raw);            // [tap][co][4 quads]
+    f32x4* pt = wl + WQ;                                        // [py][px][4 quads]
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, kq = lane >> 4;
+
+    // block -> (co tile, image, tile row, tile col); XCD-contiguous so neighbouring tiles share halos in one L2
+    int t = xcd_contiguous_block(blockIdx.x, gridDim.x);
+    const int tiles_x = p.W / TW, tiles_y = (p.H + TH - 1) / TH;
+    const int tx = t % tiles_x; t /= tiles_x;
+    const int ty = t % tiles_y; t /= tiles_y;
+    const int b = t % p.B;
+    const int co_tile = t / p.B;
+    const int co0 = co_tile * NCO, x0 = tx * TW, y0 = ty * TH;
+
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
+    const __amdgpu_buffer_rsrc_t wr = make_rsrc(p.wp, p.w_bytes);
+    const int CB = p.cb_per_tap;
+
+    // WINO: a wave's FPX rows are processed as pairs: fragment column r16 = pair index 0..7 of row (2 rows per fragment)
+    f32x4 acc[WINO ? 4 : 1][FCO][FPX];
+#pragma unroll
+    for (int xi = 0; xi < (WINO ? 4 : 1); ++xi)
+#pragma unroll
+        for (int i = 0; i < FCO; ++i)
+#pragma unroll
+            for (int j = 0; j < FPX; ++j) acc[xi][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // Register-staged double buffering: the global loads of stage cb+1 are issued before the MFMAs of stage cb and land in
+    // registers while the matrix pipe works; they are written to LDS after the barrier that retires stage cb's reads.
+    constexpr int WPT = (WQ + 255) / 256;       // weight quads per thread per stage
+    constexpr int PPT = (PQ + 255) / 256;       // patch quads per thread per stage
+    f32x4 rw[WPT], rp[PPT];
+    auto stage_load = [&](int cb) {
+#pragma unroll
+        for (int u = 0; u < WPT; ++u) {
+            const int q = tid + 256 * u;
+            const int tap = q / (NCO * 4), rem = q - tap * (NCO * 4);
+            uint32_t off;
+            if (!WINO) off = (uint32_t)(((tap * CB + cb) * p.Cout + co0) * 16 + rem * 4) * 4u;                       // [tap][cb][Cout][16]
+            else off = (uint32_t)(((((tap >> 2) * CB + cb) * 4 + (tap & 3)) * p.Cout + co0) * 16 + rem * 4) * 4u;   // [kh][cb][xi][Cout][16]
+            rw[u] = buf_load4(wr, q < WQ ? off : 0x80000000u);
+        }
+#pragma unroll
+        for (int u = 0; u < PPT; ++u) {
+            const int q = tid + 256 * u;
+            const int quad = q & 3, pix = q >> 2;
+            const int py = pix / PWID, px = pix - py * PWID;
+            const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+            const bool ok = (q < PQ) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+            rp[u] = buf_load4(xr, ok ? (uint32_t)(((b * p.H + iy) * p.W + ix) * p.Cs + cb * 16 + quad * 4) * 4u : 0x80000000u);
+        }
+    };
+    auto stage_store = [&]() {
+#pragma unroll
+        for (int u = 0; u < WPT; ++u)
+            if (tid + 256 * u < WQ) wl[tid + 256 * u] = rw[u];
+#pragma unroll
+        for (int u = 0; u < PPT; ++u)
+            if (tid + 256 * u < PQ) pt[tid + 256 * u] = rp[u];
+    };
+    stage_load(0);
+    stage_store();
+    for (int cb = 0; cb < CB; ++cb) {
+        if (cb + 1 < CB) stage_load(cb + 1);
+        __syncthreads();
+
+        // ---- sweep the taps out of LDS ------------------------------------------------------------------------------------
+        if (!WINO) {
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    f32x4 a[FCO], bb[FPX];
+#pragma unroll
+                    for (int i = 0; i < FCO; ++i) a[i] = wl[((kh * 3 + kw) * NCO + 16 * i + r16) * 4 + kq];
+#pragma unroll
+                    for (int j = 0; j < FPX; ++j) bb[j] = pt[((wave * FPX + j + kh) * PWID + r16 + kw) * 4 + kq];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int i = 0; i < FCO; ++i)
+#pragma unroll
+                            for (int j = 0; j < FPX; ++j)
+                                acc[0][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][k], bb[j][k], acc[0][i][j], 0, 0, 0);
+                }
+        } else {
+            // fragment j of a wave covers 2 tile rows x 8 pairs: lane r16 -> (row = r16 >> 3, pair = r16 & 7)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                f32x4 v[4][FPX];
+#pragma unroll
+                for (int j = 0; j < FPX; ++j) {
+                    const int prow = wave * FPX * 2 + 2 * j + (r16 >> 3) + kh;     // patch row
+                    const int pcol = 2 * (r16 & 7);                                   // patch col of d0 (= ox0 - 1 - (x0 - 1))
+                    const f32x4* src = pt + (prow * PWID + pcol) * 4 + kq;
+                    const f32x4 d0 = src[0], d1 = src[4], d2 = src[8], d3 = src[12];
+                    v[0][j] = d0 - d2; v[1][j] = d1 + d2; v[2][j] = d2 - d1; v[3][j] = d1 - d3;
+                }
+#pragma unroll
+                for (int xi = 0; xi < 4; ++xi) {
+                    f32x4 a[FCO];
+#pragma unroll
+                    for (int i = 0; i < FCO; ++i) a[i] = wl[((kh * 4 + xi) * NCO + 16 * i + r16) * 4 + kq];
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int i = 0; i < FCO; ++i)
+#pragma unroll
+                            for (int j = 0; j < FPX; ++j)
+                                acc[xi][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][k], v[xi][j][k], acc[xi][i][j], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();                         // every wave is done reading this stage
+        if (cb + 1 < CB) stage_store();
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------------------------------------
+    const int hw = p.H * p.W;
+    if (!WINO) {
+#pragma unroll
+        for (int j = 0; j < FPX; ++j) {
+            const int oy = y0 + wave * FPX + j, ox = x0 + r16;
+            const bool ok = oy < p.H;                       // W is a multiple of 16
+            const int m = (b * p.H + (ok ? oy : 0)) * p.W + ox;
+            f32x4 y[FCO];
+#pragma unroll
+            for (int i = 0; i < FCO; ++i) y[i] = conv_epilogue(acc[0][i][j], p, co0 + 16 * i + 4 * kq, (size_t)m, b);
+            if (p.proj_w != nullptr) {
+                const float* wlp = p.proj_w + co0 + 4 * kq;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    float s0 = 0.f;
+#pragma unroll
+                    for (int i = 0; i < FCO; ++i) {
+                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(wlp + tap * p.Cout + 16 * i);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) s0 = fmaf(y[i][e], w4[e], s0);
+                    }
+                    s0 += __shfl_xor(s0, 16, 64);
+                    s0 += __shfl_xor(s0, 32, 64);
+                    if (ok && kq == (tap & 3)) p.proj_out[(size_t)tap * p.M + m] = s0;
+                }
+            } else if (ok) {
+#pragma unroll
+                for (int i = 0; i < FCO; ++i) *reinterpret_cast<f32x4*>(p.out + (size_t)m * p.Cout + co0 + 16 * i + 4 * kq) = y[i];
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < FPX; ++j) {
+            const int oy = y0 + wave * FPX * 2 + 2 * j + (r16 >> 3), ox = x0 + 2 * (r16 & 7);
+            const bool ok = oy < p.H;
+            const int m = (b * p.H + (ok ? oy : 0)) * p.W + ox;
+            f32x4 y0v[FCO], y1v[FCO];
+#pragma unroll
+            for (int i = 0; i < FCO; ++i) {
+                const int co = co0 + 16 * i + 4 * kq;
+                y0v[i] = conv_epilogue(acc[0][i][j] + acc[1][i][j] + acc[2][i][j], p, co, (size_t)m, b);
+                y1v[i] = conv_epilogue(acc[1][i][j] - acc[2][i][j] - acc[3][i][j], p, co, (size_t)m + 1, b);
+            }
+            if (p.proj_w != nullptr) {
+                const float* wlp = p.proj_w + co0 + 4 * kq;
+#pragma unroll
+                for (int tap = 0; tap < 9; ++tap) {
+                    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+                    for (int i = 0; i < FCO; ++i) {
+                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(wlp + tap * p.Cout + 16 * i);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) { s0 = fmaf(y0v[i][e], w4[e], s0); s1 = fmaf(y1v[i][e], w4[e], s1); }
+                    }
+                    s0 += __shfl_xor(s0, 16, 64); s0 += __shfl_xor(s0, 32, 64);
+                    s1 += __shfl_xor(s1, 16, 64); s1 += __shfl_xor(s1, 32, 64);
+                    if (ok && kq == (tap & 3)) {
+                        p.proj_out[(size_t)tap * p.M + m] = s0;
+                        p.proj_out[(size_t)tap * p.M + m + 1] = s1;
+                    }
+                }
+            } else if (ok) {
+#pragma unroll
+                for (int i = 0; i < FCO; ++i) {
+                    const int co = co0 + 16 * i + 4 * kq;
+                    *reinterpret_cast<f32x4*>(p.out + (size_t)m * p.Cout + co) = y0v[i];
+                    *reinterpret_cast<f32x4*>(p.out + ((size_t)m + 1) * p.Cout + co) = y1v[i];
+                }
+            }
+        }
+    }
+    (void)hw;
+}
+
+}  // namespace
+
+// cfg: fco in {2,4}; fpx = tile rows per wave (direct: 1,2,4 -> tile 4/8/16 rows; Winograd: rows per wave = 2*fpx);
+// cfg.wino selects the Winograd slab (p.wp must then be the Winograd pack).  W must be a multiple of 16.
+int sbgm_launch_conv_lds(ConvParams p, const ConvTile& cfg, hipStream_t st) {
+    SBGM_CHECK(p.Cs % 16 == 0 && p.W % 16 == 0, "conv_lds: needs Cin padded to 16 and W %% 16 == 0 (Cs=%d W=%d)", p.Cs, p.W);
+    SBGM_CHECK(p.Cout % (16 * cfg.fco) == 0, "conv_lds: Cout=%d not a multiple of the %d-channel tile", p.Cout, 16 * cfg.fco);
+    SBGM_CHECK(p.act == SBGM_ACT_NONE || p.act == SBGM_ACT_RELU || p.act == SBGM_ACT_GELU, "conv_lds: act=%d does not fuse", p.act);
+    SBGM_CHECK((size_t)p.B * p.H * p.W * p.Cs * 4 < (1ull << 31), "conv_lds: input tensor exceeds 2 GiB buffer window");
+    SBGM_CHECK(p.proj_w == nullptr || (p.Cout == 16 * cfg.fco && p.proj_out != nullptr), "conv_lds: tap projection needs one co tile");
+    p.OH = p.H; p.OW = p.W;
+    p.M = p.B * p.H * p.W;
+    p.cb_per_tap = p.Cs / 16;
+    p.nsteps = 9 * p.cb_per_tap;
+    p.x_bytes = (uint32_t)((size_t)p.B * p.H * p.W * p.Cs * 4);
+    p.w_bytes = (uint32_t)((cfg.wino ? sbgm_wino_packed_floats(p.Cout, p.Cs) : (size_t)9 * p.cb_per_tap * p.Cout * 16) * 4);
+    const int rows_per_wave = cfg.wino ? 2 * cfg.fpx : cfg.fpx;
+    const int TH = 4 * rows_per_wave;
+    const int tiles = (p.W / 16) * ((p.H + TH - 1) / TH) * p.B * (p.Cout / (16 * cfg.fco));
+    const int ntap = cfg.wino ? 12 : 9;
+    const size_t lds = ((size_t)ntap * 16 * cfg.fco * 4 + (size_t)(TH + 2) * 18 * 4) * 16;
+    int rc = 1;
+#define SBGM_L(FC, FP, WN)                                                                                  \
+    if (cfg.fco == FC && cfg.fpx == FP && (cfg.wino != 0) == WN) {                                            \
+        if (lds > 64 * 1024)                                                                                  \
+            SBGM_HIP(hipFuncSetAttribute((const void*)conv3x3_lds_kernel<FC, FP, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((conv3x3_lds_kernel<FC, FP, WN>), dim3(tiles), dim3(256), lds, st, p);           \
+        rc = 0;                                                                                              \
+    }
+    SBGM_L(4, 1, false) SBGM_L(4, 2, false) SBGM_L(4, 4, false) SBGM_L(2, 2, false) SBGM_L(2, 4, false)
+    SBGM_L(4, 1, true) SBGM_L(4, 2, true) SBGM_L(2, 1, true) SBGM_L(2, 2, true)
+#undef SBGM_L
+    SBGM_CHECK(rc == 0, "conv_lds: no kernel for tile fco=%d fpx=%d wino=%d", cfg.fco, cfg.fpx, cfg.wino);
+    SBGM_LAUNCH_CHECK();
+    return 0;
+}

@@ -13,6 +13,7 @@ struct ConvTile {
     int splits;     // split-K over gridDim.y (partials + reduce kernel)
     int ws;         // waves of a workgroup cooperating on one tile (in-workgroup split-K through LDS): 1, 2 or 4
     int wino;       // 1 = 3x3/s1 Winograd F(2,3) kernel (conv_wino.hip): fpx then counts PAIR fragments, weights = wino pack
+    int lds;        // 1 = LDS-staged 3x3/s1 kernel (conv_lds.hip): fpx = tile rows per wave (Winograd: 2*fpx rows)
 };
 struct ConvParams {
     const float* x;       // NHWC [B][H][W][Cs]
@@ -44,6 +45,9 @@ int sbgm_launch_conv(const ConvGeom& g, ConvParams p, const ConvTile& cfg, float
 size_t sbgm_wino_packed_floats(int Cout, int cs);
 int sbgm_launch_pack_wino_weight(const float* w_oihw, float* up, int Cout, int Cin, int cs, hipStream_t st);
 int sbgm_launch_conv_wino(ConvParams p, const ConvTile& cfg, hipStream_t st);   // p.wp = Winograd-packed weights
+
+// ---- conv_lds.hip: 3x3 stride-1 pad-1 convolution with LDS-staged halo patch + weight slab (direct or Winograd) -----------
+int sbgm_launch_conv_lds(ConvParams p, const ConvTile& cfg, hipStream_t st);
 
 // ---- pointwise.hip ---------------------------------------------------------------------------------
 struct PackSrc {

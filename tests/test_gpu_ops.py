@@ -123,20 +123,24 @@ def test_conv_gelu_epilogue_and_combined_splits():
         assert relerr(got, want) < 2e-5, kw
 
 
-def run_wino(x, w, tile, wpt, scale=None, bias=None, tbias=None, res=None, relu=False, after=False):
+def run_wino(x, w, tile, wpt, scale=None, bias=None, tbias=None, res=None, relu=False, after=False, mode=1):
     B, Cin, H, W = x.shape
     Cout = w.shape[0]
     cp = pad_c(Cin)
     xp = torch.zeros(B, H, W, cp)
     xp[..., :Cin] = nhwc(x)
     xd, wd = xp.to(DEV), w.contiguous().to(DEV)
-    packed = torch.empty(lib().sbgm_conv_wino_packed_numel(Cout, cp), device=DEV)
-    N.check(lib().sbgm_conv_wino_pack_weight(wd.data_ptr(), packed.data_ptr(), Cout, Cin, cp, N.stream()))
+    if mode & 1:
+        packed = torch.empty(lib().sbgm_conv_wino_packed_numel(Cout, cp), device=DEV)
+        N.check(lib().sbgm_conv_wino_pack_weight(wd.data_ptr(), packed.data_ptr(), Cout, Cin, cp, N.stream()))
+    else:
+        packed = torch.empty(lib().sbgm_conv_packed_numel(Cout, 3, 3, cp), device=DEV)
+        N.check(lib().sbgm_conv_pack_weight(wd.data_ptr(), packed.data_ptr(), Cout, Cin, 3, 3, cp, N.stream()))
     out = torch.empty(B, H, W, Cout, device=DEV)
     dv = lambda t: None if t is None else t.contiguous().to(DEV)  # noqa: E731
     sc, bi, tb, rs = dv(scale), dv(bias), dv(tbias), dv(None if res is None else nhwc(res))
     a = N.ConvArgs(xd.data_ptr(), packed.data_ptr(), out.data_ptr(), N.ptr(sc), N.ptr(bi), N.ptr(tb), N.ptr(rs), B, H, W, cp, Cout, 3, 3, 1, 1,
-                   N.RELU if relu else N.NONE, int(after), tile[0], tile[1], 0, wpt, 1, 0, 0, 0, None, 0)
+                   N.RELU if relu else N.NONE, int(after), tile[0], tile[1], 0, wpt, mode, 0, 0, 0, None, 0)
     N.check(lib().sbgm_conv2d_fwd(C.byref(a), N.stream()))
     torch.cuda.synchronize()
     return nchw(out.cpu())
@@ -151,6 +155,17 @@ def test_conv_winograd_f23(shape, tile, wpt):
     x, w = rnd(B, Cin, H, W), rnd(Cout, Cin, 3, 3, seed=1, scale=1.0 / math.sqrt(Cin * 9))
     got = run_wino(x, w, tile, wpt)
     assert relerr(got, ref_conv(x, w, 1, 1)) < 2e-5
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 8, 16, 64), (1, 64, 16, 32, 128), (2, 128, 12, 16, 64), (1, 16, 20, 48, 64), (1, 256, 4, 16, 64)])
+@pytest.mark.parametrize("mode,tile", [(2, (4, 1)), (2, (4, 2)), (2, (4, 4)), (2, (2, 2)), (2, (2, 4)), (3, (4, 1)), (3, (4, 2)), (3, (2, 1)),
+                                       (3, (2, 2))])
+def test_conv_lds_staged(shape, mode, tile):
+    B, Cin, H, W, Cout = shape
+    x, w = rnd(B, Cin, H, W), rnd(Cout, Cin, 3, 3, seed=1, scale=1.0 / math.sqrt(Cin * 9))
+    kw = dict(bias=rnd(Cout, seed=4), res=rnd(B, Cout, H, W, seed=6), relu=True)
+    got = run_wino(x, w, tile, 0, mode=mode, **kw)
+    assert relerr(got, ref_conv(x, w, 1, 1, **kw)) < 2e-5
 
 
 def test_conv_winograd_epilogue():
