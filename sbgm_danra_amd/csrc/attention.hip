@@ -16,15 +16,19 @@
 
 namespace {
 
-template <int D16>   // head dim = 16 * D16
+// KSPLIT = 1: one wave per 16-query block, all keys.  KSPLIT = 4: the 4 waves of a workgroup share one query block and take
+// the key blocks round-robin (4x shorter dependent load->MFMA->softmax chains at S >= 64); their (max, sum, O^T) partials
+// are merged through LDS with the usual online-softmax rescale.
+template <int D16, int KSPLIT>   // head dim = 16 * D16
 __global__ __launch_bounds__(256) void mha_core_kernel(const float* __restrict__ qkv, float* __restrict__ out, int B,
                                                        int S, int C, int heads, float scale) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r16 = lane & 15, kq = lane >> 4;
     const int qblocks = (S + 15) >> 4;
-    int w = blockIdx.x * 4 + wave;
-    if (w >= B * heads * qblocks) return;
+    int w = KSPLIT == 1 ? blockIdx.x * 4 + wave : blockIdx.x;
+    if (w >= B * heads * qblocks) return;        // whole workgroup when KSPLIT > 1
     const int qb = w % qblocks; w /= qblocks;
     const int h = w % heads;
     const int b = w / heads;
@@ -48,7 +52,7 @@ __global__ __launch_bounds__(256) void mha_core_kernel(const float* __restrict__
     for (int j = 0; j < D16; ++j) o[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     float m_run = -INFINITY, l_run = 0.f;
 
-    for (int k0 = 0; k0 < S; k0 += 16) {
+    for (int k0 = (KSPLIT == 1 ? 0 : wave * 16); k0 < S; k0 += 16 * KSPLIT) {
         // ---- S^T block: rows = keys k0..k0+15, cols = queries --------------------------------------------
         const int krow = k0 + r16;                       // A operand row this lane loads
         const bool k_ok = krow < S;
@@ -94,6 +98,31 @@ __global__ __launch_bounds__(256) void mha_core_kernel(const float* __restrict__
             }
         }
     }
+    if (KSPLIT > 1) {
+        // merge the waves' partial softmax states; a wave that saw no key block carries m = -inf, l = 0, O = 0
+        float* ml = reinterpret_cast<float*>(smem_raw);                       // [wave][64 lanes][2]
+        f32x4* ol = reinterpret_cast<f32x4*>(smem_raw + 4 * 64 * 2 * 4);      // [wave][D16][64 lanes]
+        ml[(wave * 64 + lane) * 2] = m_run;
+        ml[(wave * 64 + lane) * 2 + 1] = l_run;
+#pragma unroll
+        for (int j = 0; j < D16; ++j) ol[(wave * D16 + j) * 64 + lane] = o[j];
+        __syncthreads();
+        if (wave != 0) return;
+        float m_all = m_run;
+#pragma unroll
+        for (int ww = 1; ww < 4; ++ww) m_all = fmaxf(m_all, ml[(ww * 64 + lane) * 2]);
+        float f0 = expf(m_run - m_all);
+        l_run *= f0;
+#pragma unroll
+        for (int j = 0; j < D16; ++j) o[j] *= f0;
+#pragma unroll
+        for (int ww = 1; ww < 4; ++ww) {
+            const float fw = expf(ml[(ww * 64 + lane) * 2] - m_all);          // exp(-inf) = 0 for idle waves
+            l_run += ml[(ww * 64 + lane) * 2 + 1] * fw;
+#pragma unroll
+            for (int j = 0; j < D16; ++j) o[j] += ol[(ww * D16 + j) * 64 + lane] * fw;
+        }
+    }
     if (q_ok) {
         const float inv = 1.f / l_run;
         float* op = out + ((size_t)b * S + qi) * C + (size_t)h * d;
@@ -109,12 +138,19 @@ int sbgm_launch_mha_core(const float* qkv, float* out, int B, int S, int C, int 
     const int d = C / heads;
     SBGM_CHECK(d % 16 == 0 && d <= 512, "mha: head dim %d must be a multiple of 16 (<= 512)", d);
     const int waves = B * heads * ((S + 15) / 16);
-    const dim3 grid((waves + 3) / 4), block(256);
+    const bool ksplit = S >= 64 && d <= 256;             // >= 4 key blocks: spread them over the 4 waves of a workgroup
+    const dim3 grid(ksplit ? waves : (waves + 3) / 4), block(256);
+    const size_t lds = ksplit ? (size_t)4 * 64 * 2 * 4 + (size_t)4 * (d / 16) * 64 * 16 : 0;
     const float scale = 1.0f / sqrtf((float)d);
     switch (d / 16) {
-#define SBGM_MHA(N) case N: hipLaunchKernelGGL(mha_core_kernel<N>, grid, block, 0, st, qkv, out, B, S, C, heads, scale); break;
-        SBGM_MHA(1) SBGM_MHA(2) SBGM_MHA(3) SBGM_MHA(4) SBGM_MHA(6) SBGM_MHA(8) SBGM_MHA(12) SBGM_MHA(16) SBGM_MHA(32)
+#define SBGM_MHA(N)                                                                                                      \
+    case N:                                                                                                              \
+        if (ksplit) hipLaunchKernelGGL((mha_core_kernel<N, 4>), grid, block, lds, st, qkv, out, B, S, C, heads, scale);    \
+        else hipLaunchKernelGGL((mha_core_kernel<N, 1>), grid, block, 0, st, qkv, out, B, S, C, heads, scale);             \
+        break;
+        SBGM_MHA(1) SBGM_MHA(2) SBGM_MHA(3) SBGM_MHA(4) SBGM_MHA(6) SBGM_MHA(8) SBGM_MHA(12) SBGM_MHA(16)
 #undef SBGM_MHA
+        case 32: hipLaunchKernelGGL((mha_core_kernel<32, 1>), dim3((waves + 3) / 4), block, 0, st, qkv, out, B, S, C, heads, scale); break;
         default: SBGM_CHECK(false, "mha: head dim %d not instantiated", d);
     }
     SBGM_LAUNCH_CHECK();

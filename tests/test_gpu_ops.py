@@ -281,7 +281,7 @@ def test_batchnorm_train(with_res):
 
 
 @pytest.mark.parametrize("B,S,C_,heads", [(2, 64, 256, 4), (2, 16, 512, 4), (1, 256, 128, 4), (3, 4, 256, 2), (1, 1024, 128, 8),
-                                          (2, 40, 128, 1)])
+                                          (2, 40, 128, 1), (2, 88, 128, 2), (1, 200, 96, 2)])
 def test_mha_core(B, S, C_, heads):
     qkv = rnd(B, S, 3 * C_)
     d = C_ // heads
