@@ -152,6 +152,8 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-autotune", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--tune-cache", default=None, help="tile-table file: loaded when present, else written after autotuning "
+                                                       "(lets the rocprofv3 passes replay exactly the benchmarked kernels)")
     ap.add_argument("--profile-csv", default=None, help="write the per-convolution event timings here")
     ap.add_argument("--mode", choices=["sample", "train"], default="sample",
                     help="sample = BASELINE configs[1] (the headline metric); train = configs[2] optimizer steps (secondary line)")
@@ -178,7 +180,7 @@ def main():
     g = torch.Generator().manual_seed(42 + rank)
     cond = torch.randn(B, 1, HW, HW, generator=g).to(dev)
     if not a.no_autotune:
-        net.autotune(B, HW, HW, cond_channels=(0, 0, 1))
+        net.autotune(B, HW, HW, cond_channels=(0, 0, 1), cache=a.tune_cache)
     sampler = S.Euler_Maruyama_sampler if a.sampler == "em" else S.pc_sampler
     evals_per_step = 1 if a.sampler == "em" else 2
     kw = dict(batch_size=B, device=dev, img_size=HW, cond_img=cond, use_graph=not a.no_graph, seed=1234 + rank)
@@ -211,22 +213,60 @@ def main():
         eng = net._engine(None, None, cond)
         prof = N.Profile()
         best = None
+        import csv
+        import tempfile
+        csv_path = a.profile_csv or os.path.join(tempfile.gettempdir(), f"sbgm_conv_profile_{os.getpid()}.csv")
         for _ in range(5):
             N.check(lib.sbgm_model_profile_forward(eng.h, x.data_ptr(), t.data_ptr(), None, cond.data_ptr(), None, None,
-                                                   o.data_ptr(), B, HW, HW, C.byref(prof),
-                                                   a.profile_csv.encode() if a.profile_csv else None, N.stream()))
+                                                   o.data_ptr(), B, HW, HW, C.byref(prof), csv_path.encode(), N.stream()))
             if best is None or prof.ms_conv < best[0]:
+                with open(csv_path) as f:
+                    rows = list(csv.DictReader(f))
                 best = (prof.ms_conv, prof.flops_conv, prof.n_conv, prof.ms_total_with_events, prof.ms_conv_max,
-                        prof.flops_conv_max)
-        ms_conv, fl_conv, n_conv, ms_tot, ms_max, fl_max = best
+                        prof.flops_conv_max, rows)
+        ms_conv, fl_conv, n_conv, ms_tot, ms_max, fl_max, rows = best
+        if not a.profile_csv:
+            os.unlink(csv_path)
+        # group the launches by kernel instantiation, the way `rocprofv3 --stats` does (profiles/r01_bench_kernel_stats.csv)
+        per = {}
+        for r in rows:
+            k = per.setdefault(r["kernel"].replace(";", ","), {"launches": 0, "ms": 0.0, "gflop": 0.0, "bytes": 0.0})
+            k["launches"] += 1
+            k["ms"] += float(r["ms"])
+            k["gflop"] += float(r["gflop"])
+            # algorithmic bytes of a launch: input once + output once + weights once (fp32)
+            cin, cout, kk = int(r["Cin_pad"]), int(r["Cout"]), int(r["kh"]) * int(r["kw"])
+            k["bytes"] += 4.0 * (int(r["B"]) * int(r["H"]) * int(r["W"]) * cin + int(r["M"]) * cout + kk * cin * cout)
+        kernels = [{"kernel": n, "launches": v["launches"], "avg_us": 1e3 * v["ms"] / v["launches"],
+                    "gflop_per_launch": v["gflop"] / v["launches"], "tflops": v["gflop"] / v["ms"],
+                    "alg_bytes_per_launch": v["bytes"] / v["launches"]}
+                   for n, v in sorted(per.items(), key=lambda kv: -kv[1]["ms"])]
+        dom = kernels[0]
+        # HBM-side traffic of that kernel: PMC counters cannot be read from inside this process; they come from the
+        # separately collected rocprofv3 passes (tools/collect_profiles.sh -> profiles/r01_pmc_traffic.json), if committed
+        traffic, traffic_src = None, None
+        for tag in ("r06", "r05", "r04", "r03", "r02", "r01"):
+            tp = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
+            if os.path.exists(tp):
+                with open(tp) as f:
+                    ent = json.load(f)["kernels"].get(dom["kernel"])
+                if ent and B == 32 and HW == 128:
+                    traffic, traffic_src = ent["bytes_per_launch"], f"profiles/{tag}_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE)"
+                break
         ach = fl_conv / (ms_conv * 1e-3) * 1e-12
         ms_eval = dt / (a.steps * evals_per_step) * 1e3
         flops_eval = FLOP_PER_SAMPLE_128 * B * (HW / 128.0) ** 2
-        roof = {"bound": "mfma", "kernel": "conv_igemm_kernel<KH,KW,S,PAD,FCO,FPX> (fp32 v_mfma_f32_16x16x4_f32), all "
-                                           f"{n_conv} launches of one evaluation",
-                "achieved": ach, "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS, "traffic": None,
-                "ms_conv_per_eval": ms_conv, "gflop_conv_per_eval": fl_conv * 1e-9,
+        # top level = the single kernel instantiation with the largest share of an evaluation; `conv_family` = all convolution
+        # launches of one evaluation (3 kernel templates, fp32 v_mfma_f32_16x16x4_f32); `kernels` = every instantiation.
+        roof = {"bound": "mfma", "kernel": dom["kernel"], "launches_per_eval": dom["launches"], "avg_launch_us": dom["avg_us"],
+                "gflop_per_launch": dom["gflop_per_launch"],
+                "achieved": dom["tflops"], "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_FP32_TFLOPS,
+                "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+                "alg_bytes_per_launch": dom["alg_bytes_per_launch"],
+                "conv_family": {"launches": n_conv, "ms_per_eval": ms_conv, "gflop_per_eval": fl_conv * 1e-9, "achieved": ach,
+                                "frac": ach / PEAK_FP32_TFLOPS},
                 "slowest_launch": {"ms": ms_max, "tflops": fl_max / (ms_max * 1e-3) * 1e-12},
+                "kernels": kernels,
                 "whole_eval": {"ms": ms_eval, "gflop": flops_eval * 1e-9,
                                "fp32_frac": flops_eval / (ms_eval * 1e-3) / (PEAK_FP32_TFLOPS * 1e12),
                                "hbm_frac_layer_fused_bytes": BYTES_PER_EVAL(B, HW) / (ms_eval * 1e-3) / (PEAK_HBM_GBS * 1e9)}}

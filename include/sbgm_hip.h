@@ -99,6 +99,10 @@ int sbgm_sampler_run(sbgm_model* m, const sbgm_sampler_args* a, void* stream);
 /* Conv autotuning: time the tile / split-K candidates of every convolution of the (B,H,W) plan once and keep the
  * fastest.  Synchronises the stream.  Optional; without it a static heuristic is used. */
 int sbgm_model_autotune(sbgm_model* m, int B, int H, int W, void* stream);
+/* Persist / restore the tuned tile table (text file) so a service tunes once per problem size, not once per process.
+ * Load merges into the current table; malformed lines are an error and leave the table untouched. */
+int sbgm_model_tune_save(sbgm_model* m, const char* path);
+int sbgm_model_tune_load(sbgm_model* m, const char* path);
 /* Eager forward with each convolution launch bracketed by HIP events on `stream` (synchronises).  csv_path (host
  * string, may be NULL) receives one line per convolution. */
 typedef struct sbgm_profile {

@@ -61,6 +61,8 @@ SIGNATURES = {
     "sbgm_model_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp), _i, _i, _i, _i, _vp]),
     "sbgm_sampler_run": (_i, [_vp, C.POINTER(SamplerArgs), _vp]),
     "sbgm_model_autotune": (_i, [_vp, _i, _i, _i, _vp]),
+    "sbgm_model_tune_save": (_i, [_vp, C.c_char_p]),
+    "sbgm_model_tune_load": (_i, [_vp, C.c_char_p]),
     "sbgm_model_profile_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, C.POINTER(Profile), C.c_char_p, _vp]),
     "sbgm_event_create": (_i, [C.POINTER(_vp)]),
     "sbgm_event_record": (_i, [_vp, _vp]),

@@ -347,11 +347,18 @@ class ScoreNet(nn.Module):
                             f"σ ∈ [{s.min():.4g}, {s.max():.4g}]")
         return out
 
-    def autotune(self, batch: int, height: int, width: int, cond_channels=(0, 0, 1)):
-        """time the conv tile candidates for this problem size once (optional)"""
+    def autotune(self, batch: int, height: int, width: int, cond_channels=(0, 0, 1), cache: str = None):
+        """time the conv tile candidates for this problem size once (optional).  `cache`: path of a tile-table file;
+        when it exists it is loaded instead of tuning, otherwise the tuned table is written there."""
+        import os
         shapes = [None if c == 0 else torch.empty(1, c, 1, 1) for c in cond_channels]
         eng = self._engine(*shapes)
+        if cache and os.path.exists(cache):
+            N.check(eng.lib.sbgm_model_tune_load(eng.h, os.fsencode(cache)))
+            return
         N.check(eng.lib.sbgm_model_autotune(eng.h, batch, height, width, N.stream()))
+        if cache:
+            N.check(eng.lib.sbgm_model_tune_save(eng.h, os.fsencode(cache)))
 
 
 def _sigma_of(fn) -> float:

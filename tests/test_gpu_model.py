@@ -144,6 +144,25 @@ def test_graph_replay_equals_eager_and_seed_reproducible():
     assert torch.isfinite(a).all() and not torch.equal(a, c)
 
 
+def test_tile_table_save_load_roundtrip(tmp_path):
+    """autotune -> save; a second model loads the table (no tuning) and evaluates bit-identically; a corrupt file is an error"""
+    from sbgm_danra_amd._native import NativeError
+    _, a, _ = build_pair(1)
+    _, b, _ = build_pair(1)
+    a.eval(), b.eval()
+    path = str(tmp_path / "tiles.txt")
+    a.autotune(2, 64, 64, cache=path)
+    assert os.path.getsize(path) > 200
+    b.autotune(2, 64, 64, cache=path)                  # loads
+    x, c, t = torch.randn(2, 1, 64, 64).cuda(), torch.randn(2, 1, 64, 64).cuda(), torch.tensor([0.2, 0.7]).cuda()
+    with torch.no_grad():
+        assert torch.equal(a(x, t, cond_img=c), b(x, t, cond_img=c))
+    bad = str(tmp_path / "bad.txt")
+    open(bad, "w").write("3 3 1 1 2 64 64 64 64 0 | 7 1 1 1 0 0\n")
+    with pytest.raises(NativeError):
+        b.autotune(2, 64, 64, cache=bad)
+
+
 def test_full_size_properties_b32_128():
     """BASELINE config 2 shape (B=32, 128x128, 1 condition): size-independent properties instead of an oracle run:
     samples are independent in eval mode (row i of a batched evaluation == the same row evaluated alone),
