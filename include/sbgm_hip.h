@@ -73,7 +73,10 @@ int sbgm_model_forward(sbgm_model* m, const float* x, const float* t, const int6
                        int W, int bn_train, void* stream);
 
 /* Whole reverse-SDE sampling loop on the device.  Replaces Euler_Maruyama_sampler / pc_sampler
- * (reference score_sampling.py:63-127, :136-230) when classifier-free guidance is off.
+ * (reference score_sampling.py:63-127, :136-230), including the classifier-free-guidance branch (guided_score_fn,
+ * :10-56): with cfg_enabled the conditional and the unconditional evaluation of a step run as ONE batch of 2B samples
+ * (rows B..2B-1: null class 0, zeroed cond_img, mask channel of the 2-channel geo fields zeroed) and are combined as
+ * (1+w) s_c - w s_u.
  *   noise: NULL -> in-kernel Philox draws keyed by `seed`; else [n_draws][B][1][H][W] host-ordered N(0,1) draws
  *          consumed as the reference consumes torch.randn: init, then per step (corrector,) predictor.
  *   out:   x_mean after the last step, NCHW [B,1,H,W].
@@ -93,6 +96,9 @@ typedef struct sbgm_sampler_args {
     const float* topo_cond;
     const float* noise;
     float* out;
+    int cfg_enabled;         /* classifier-free guidance on (cfg['classifier_free_guidance']['enabled']) */
+    float cfg_scale;         /* guidance weight w of the predictor / Euler-Maruyama evaluation */
+    float cfg_scale_corrector; /* w of the PC corrector evaluation (the reference clamps only this one to guidance_scale_max, :184-186) */
 } sbgm_sampler_args;
 int sbgm_sampler_run(sbgm_model* m, const sbgm_sampler_args* a, void* stream);
 

@@ -204,6 +204,30 @@ report["cfg"] = maxrel(b_, a)
 assert report["cfg"] <= 1e-6
 np.savez_compressed(os.path.join(GOLD, "cfg_b2_32_c6_y.npz"), **npz({**inp, "guided": a}))
 
+# samplers with live classifier-free guidance (score_sampling.py:105-118, :179-222): 6 conditioning channels + class labels
+gcfg = {"classifier_free_guidance": {"enabled": True, "guidance_scale": 2.5, "guidance_scale_max": 1.5}}
+kw = dict(y=inp["y"], cond_img=inp["cond_img"], lsm_cond=inp["lsm_cond"], topo_cond=inp["topo_cond"], cfg=gcfg)
+torch.manual_seed(9)
+xr = RS.pc_sampler(ref, R.marginal_prob_std_fn, R.diffusion_coeff_fn, batch_size=2, num_steps=2, device="cpu", img_size=32, **kw)
+torch.manual_seed(9)
+xo = O.pc_sampler(ora, O.marginal_prob_std_fn, O.diffusion_coeff_fn, batch_size=2, num_steps=2, device="cpu", img_size=32, **kw)
+report["pc_sampler_cfg"] = maxrel(xo, xr)
+assert report["pc_sampler_cfg"] <= 1e-6
+torch.manual_seed(9)
+noise = [torch.randn(2, 1, 32, 32) for _ in range(5)]
+np.savez_compressed(os.path.join(GOLD, "pc_cfg_b2_32_2steps.npz"),
+                    **npz({**{k: inp[k] for k in ("y", "cond_img", "lsm_cond", "topo_cond")}, "noise": torch.stack(noise), "x_mean": xr}))
+torch.manual_seed(10)
+xr = RS.Euler_Maruyama_sampler(ref, R.marginal_prob_std_fn, R.diffusion_coeff_fn, batch_size=2, num_steps=3, device="cpu", **kw)
+torch.manual_seed(10)
+xo = O.Euler_Maruyama_sampler(ora, O.marginal_prob_std_fn, O.diffusion_coeff_fn, batch_size=2, num_steps=3, device="cpu", **kw)
+report["em_sampler_cfg"] = maxrel(xo, xr)
+assert report["em_sampler_cfg"] <= 1e-6
+torch.manual_seed(10)
+noise = [torch.randn(2, 1, 32, 32) for _ in range(4)]
+np.savez_compressed(os.path.join(GOLD, "em_cfg_b2_32_3steps.npz"),
+                    **npz({**{k: inp[k] for k in ("y", "cond_img", "lsm_cond", "topo_cond")}, "noise": torch.stack(noise), "mean_x": xr}))
+
 with open(os.path.join(GOLD, "state_manifest.json"), "w") as f:
     json.dump(state_manifest, f, indent=0, sort_keys=True)
 with open(os.path.join(GOLD, "oracle_vs_reference.json"), "w") as f:

@@ -30,7 +30,8 @@ class ModelConfig(C.Structure):
 class SamplerArgs(C.Structure):
     _fields_ = [("kind", _i), ("B", _i), ("H", _i), ("W", _i), ("num_steps", _i), ("eps", _f), ("snr", _f),
                 ("seed", _u64), ("use_graph", _i), ("bn_train", _i), ("y", _vp), ("cond_img", _vp), ("lsm_cond", _vp),
-                ("topo_cond", _vp), ("noise", _vp), ("out", _vp)]
+                ("topo_cond", _vp), ("noise", _vp), ("out", _vp), ("cfg_enabled", _i), ("cfg_scale", _f),
+                ("cfg_scale_corrector", _f)]
 
 
 class Profile(C.Structure):

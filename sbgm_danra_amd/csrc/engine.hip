@@ -674,8 +674,10 @@ int sbgm_model::sampler(const sbgm_sampler_args& a, hipStream_t caller) {
     SBGM_CHECK(a.num_steps >= 2, "sampler: num_steps=%d must be >= 2 (step size = t0 - t1)", a.num_steps);
     SBGM_CHECK(a.out != nullptr, "sampler: out is required");
     const int B = a.B, H = a.H, W = a.W, N = a.num_steps;
+    const bool guided = a.cfg_enabled != 0;
+    const int BE = guided ? 2 * B : B;                     // samples per network evaluation
     const size_t per = (size_t)H * W, n = (size_t)B * per;
-    SBGM_CHECK(ws_need(B, H, W) <= ws_bytes, "sampler: workspace not prepared for B=%d H=%d W=%d", B, H, W);
+    SBGM_CHECK(ws_need(BE, H, W) <= ws_bytes, "sampler: workspace not prepared for B=%d H=%d W=%d", BE, H, W);
     // ---- per-step scalars on the host, in the reference's precision --------------------------------------------------
     std::vector<StepScalars> tab(N);
     const float sig = cfg.sigma;
@@ -709,15 +711,51 @@ int sbgm_model::sampler(const sbgm_sampler_args& a, hipStream_t caller) {
     SBGM_HIP(hipStreamSynchronize(st));                   // tab is a stack-lifetime host buffer
 
     // persistent sampler buffers live at the top of the workspace, the forward uses the rest
-    const size_t keep = sampler_keep(B, H, W);
+    // layout (BE = B, or 2B with guidance): x [BE*per] (rows B.. mirror rows 0..B-1), score [BE*per], x_mean [B*per]
+    const size_t keep = sampler_keep(BE, H, W);
+    const size_t slab = align_up((size_t)BE * per * 4, 256);
     char* top = ws + ws_bytes - keep;
     float* xs = reinterpret_cast<float*>(top);
-    float* score = reinterpret_cast<float*>(top + align_up(n * 4, 256));
-    float* xmean = reinterpret_cast<float*>(top + 2 * align_up(n * 4, 256));
-    float* t_dev = reinterpret_cast<float*>(top + 3 * align_up(n * 4, 256));
-    double* sumsq = reinterpret_cast<double*>(top + 3 * align_up(n * 4, 256) + align_up((size_t)B * 4, 256));
+    float* score = reinterpret_cast<float*>(top + slab);
+    float* xmean = reinterpret_cast<float*>(top + 2 * slab);
+    float* t_dev = reinterpret_cast<float*>(top + 3 * slab);
+    double* sumsq = reinterpret_cast<double*>(top + 3 * slab + align_up((size_t)BE * 4, 256));
     const size_t fwd_bytes = ws_bytes - keep;
     if (bn_dirty && fold_bn(st)) return 1;              // keep the fold out of the captured step
+
+    // guidance: the unconditional half of the condition tensors is built once per run (guided_score_fn :27-43)
+    const int64_t* y_e = a.y;
+    const float *cond_e = a.cond_img, *lsm_e = a.lsm_cond, *topo_e = a.topo_cond;
+    struct Scratch {                                       // freed on every exit path, after the stream has drained
+        std::vector<void*> v;
+        hipStream_t st;
+        ~Scratch() {
+            if (v.empty()) return;
+            (void)hipStreamSynchronize(st);
+            for (void* p : v) (void)hipFree(p);
+        }
+    } guided_bufs{{}, st};
+    if (guided) {
+        SBGM_CHECK(!a.bn_train, "sampler: guidance with train-mode BatchNorm would couple the two halves of the batch");
+        auto dup = [&](const void* src, size_t bytes_half, int mode, int channels) -> void* {   // mode 0 zero, 1 copy, 2 strip mask
+            void* p = nullptr;
+            if (hipMalloc(&p, 2 * bytes_half) != hipSuccess) return nullptr;
+            guided_bufs.v.push_back(p);
+            (void)hipMemcpyAsync(p, src, bytes_half, hipMemcpyDeviceToDevice, st);
+            char* lo = static_cast<char*>(p) + bytes_half;
+            if (mode == 0) (void)hipMemsetAsync(lo, 0, bytes_half, st);
+            else (void)hipMemcpyAsync(lo, src, bytes_half, hipMemcpyDeviceToDevice, st);
+            if (mode == 2 && channels == 2)                  // NCHW [B][2][H][W]: zero channel 1 of every sample
+                (void)hipMemset2DAsync(lo + per * 4, 2 * per * 4, 0, per * 4, B, st);
+            return p;
+        };
+        bool ok = true;
+        if (a.y) ok = ok && (y_e = static_cast<const int64_t*>(dup(a.y, (size_t)B * 8, 0, 0)));          // null token 0
+        if (a.cond_img) ok = ok && (cond_e = static_cast<const float*>(dup(a.cond_img, n * 4 * cfg.n_cond_channels, 0, 0)));
+        if (a.lsm_cond) ok = ok && (lsm_e = static_cast<const float*>(dup(a.lsm_cond, n * 4 * cfg.n_lsm_channels, 2, cfg.n_lsm_channels)));
+        if (a.topo_cond) ok = ok && (topo_e = static_cast<const float*>(dup(a.topo_cond, n * 4 * cfg.n_topo_channels, 2, cfg.n_topo_channels)));
+        SBGM_CHECK(ok && hipGetLastError() == hipSuccess, "sampler: could not allocate the unconditional condition tensors");
+    }
 
     // x0 = randn * marginal_prob_std(1)
     const float ls = logf(sig);
@@ -726,17 +764,23 @@ int sbgm_model::sampler(const sbgm_sampler_args& a, hipStream_t caller) {
     size_t draw = 0;
     auto next_z = [&]() -> const float* { const float* p = z ? z + draw * n : nullptr; ++draw; return p; };
     if (sbgm_launch_init_noise(xs, std1, next_z(), a.seed, d_state, 0, n, st)) return 1;
-    if (sbgm_launch_fill_t(t_dev, tab[0].t, B, st)) return 1;
+    if (sbgm_launch_fill_t(t_dev, tab[0].t, BE, st)) return 1;
     const float snr_nn = (float)((double)a.snr * std::sqrt((double)per));     // snr * sqrt(prod(x.shape[1:])) (:202-203)
 
+    // one (possibly guided) score evaluation of the current x into score[0 .. n)
+    auto evaluate = [&](float w) -> int {
+        if (guided) SBGM_HIP(hipMemcpyAsync(xs + n, xs, n * 4, hipMemcpyDeviceToDevice, st));
+        if (forward(xs, t_dev, y_e, cond_e, lsm_e, topo_e, score, nullptr, BE, H, W, a.bn_train, st)) return 1;
+        return guided ? sbgm_launch_cfg_combine(score, score, score + n, w, n, st) : 0;
+    };
     auto one_step = [&](bool with_noise_ptrs) -> int {
         if (a.kind == SBGM_SAMPLER_PC) {
-            if (forward(xs, t_dev, a.y, a.cond_img, a.lsm_cond, a.topo_cond, score, nullptr, B, H, W, a.bn_train, st)) return 1;
+            if (evaluate(a.cfg_scale_corrector)) return 1;
             if (sbgm_launch_langevin(xs, score, with_noise_ptrs ? next_z() : nullptr, snr_nn, sumsq, d_state, 0, a.seed, B, per, st)) return 1;
         }
-        if (forward(xs, t_dev, a.y, a.cond_img, a.lsm_cond, a.topo_cond, score, nullptr, B, H, W, a.bn_train, st)) return 1;
+        if (evaluate(a.cfg_scale)) return 1;
         return sbgm_launch_em_update(xs, xmean, score, with_noise_ptrs ? next_z() : nullptr, d_table, d_state, nullptr, 0, t_dev,
-                                     a.seed, B, per, N, st);
+                                     a.seed, B, per, N, st, BE);
     };
 
     const size_t saved_ws = ws_bytes;
@@ -844,7 +888,7 @@ int sbgm_model_forward(sbgm_model* m, const float* x, const float* t, const int6
 
 int sbgm_sampler_run(sbgm_model* m, const sbgm_sampler_args* a, void* stream) {
     SBGM_CHECK(a, "sampler_run: null args");
-    if (m->ensure_ws(m->ws_need(a->B, a->H, a->W))) return 1;
+    if (m->ensure_ws(m->ws_need(a->cfg_enabled ? 2 * a->B : a->B, a->H, a->W))) return 1;
     return m->sampler(*a, (hipStream_t)stream);
 }
 

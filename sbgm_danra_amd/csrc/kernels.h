@@ -127,7 +127,8 @@ int sbgm_launch_init_noise(float* x, float scale, const float* z, unsigned long 
                            unsigned long long draw_index, size_t n, hipStream_t st);
 int sbgm_launch_em_update(float* x, float* x_mean, const float* score, const float* z, const StepScalars* table,
                           SamplerState* state, const StepScalars* sc_val, unsigned long long draw_index, float* t_dev,
-                          unsigned long long seed, int B, size_t per_sample, int n_steps, hipStream_t st);
+                          unsigned long long seed, int B, size_t per_sample, int n_steps, hipStream_t st,
+                          int t_entries = 0);   // entries of t_dev to refresh (0 -> B; 2B for the batched guidance pass)
 int sbgm_launch_langevin(float* x, const float* score, const float* z, float snr_noise_norm, double* sumsq_ws,
                          SamplerState* state, unsigned long long draw_index, unsigned long long seed, int B,
                          size_t per_sample, hipStream_t st);

@@ -160,17 +160,18 @@ int sbgm_launch_init_noise(float* x, float scale, const float* z, unsigned long 
 
 int sbgm_launch_em_update(float* x, float* x_mean, const float* score, const float* z, const StepScalars* table,
                           SamplerState* state, const StepScalars* sc_val, unsigned long long draw_index, float* t_dev,
-                          unsigned long long seed, int B, size_t per_sample, int n_steps, hipStream_t st) {
+                          unsigned long long seed, int B, size_t per_sample, int n_steps, hipStream_t st, int t_entries) {
     const size_t n = (size_t)B * per_sample;
+    if (t_entries <= 0) t_entries = B;
     SBGM_CHECK(n % 4 == 0, "em_update: element count must be a multiple of 4");
-    SBGM_CHECK(B <= 1024, "em_update: batch %d > 1024", B);
+    SBGM_CHECK(t_entries <= 1024, "em_update: %d time entries > 1024", t_entries);
     SBGM_CHECK(state != nullptr || sc_val != nullptr, "em_update: need a device table or explicit scalars");
     const StepScalars v = sc_val ? *sc_val : StepScalars{};
     hipLaunchKernelGGL(em_update_kernel, dim3(stream_blocks(n / 4)), dim3(256), 0, st, x, x_mean, score, z, table, state, v,
                        draw_index, seed, n / 4);
     SBGM_LAUNCH_CHECK();
     if (state) {
-        hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1024), 0, st, state, table, t_dev, B, 1, n_steps);
+        hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1024), 0, st, state, table, t_dev, t_entries, 1, n_steps);
         SBGM_LAUNCH_CHECK();
     }
     return 0;

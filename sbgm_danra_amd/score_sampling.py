@@ -71,8 +71,21 @@ def _score(score_model, cfg, x, t, y, cond_img, lsm_cond, topo_cond, clamp=False
     return score_model(x, t, y, cond_img, lsm_cond, topo_cond)
 
 
+def _guidance(cfg):
+    """(enabled, predictor scale, corrector scale): the reference clamps only the corrector's scale to
+    guidance_scale_max (score_sampling.py:184-186 vs :213)."""
+    if not _cfg_enabled(cfg):
+        return 0, 0.0, 0.0
+    g = cfg["classifier_free_guidance"]
+    scale = float(g.get("guidance_scale", 2.0))
+    corr = scale
+    if g.get("guidance_scale_max") is not None and corr > g["guidance_scale_max"]:
+        corr = float(g["guidance_scale_max"])
+    return 1, scale, corr
+
+
 def _native_run(kind, score_model: ScoreNet, batch_size, num_steps, snr, eps, hw, y, cond_img, lsm_cond, topo_cond,
-                noise, use_graph, seed, device):
+                noise, use_graph, seed, device, cfg=None):
     dev = torch.device(device) if not isinstance(device, torch.device) else device
     if dev.type != "cuda":
         raise N.NativeError(f"the native samplers run on a ROCm device, got device={device!r}")
@@ -90,7 +103,7 @@ def _native_run(kind, score_model: ScoreNet, batch_size, num_steps, snr, eps, hw
         nz = N.f32c(nz.to(dev))
     a = N.SamplerArgs(kind, batch_size, hw, hw, int(num_steps), float(eps), float(snr), int(seed), int(bool(use_graph)),
                       int(score_model.training), N.ptr(y), N.ptr(cond_img), N.ptr(lsm_cond), N.ptr(topo_cond), N.ptr(nz),
-                      out.data_ptr())
+                      out.data_ptr(), *_guidance(cfg))
     N.check(eng.lib.sbgm_sampler_run(eng.h, C.byref(a), N.stream()))
     if score_model.training:
         eng.download_bn_stats(score_model)
@@ -102,9 +115,9 @@ def Euler_Maruyama_sampler(score_model, marginal_prob_std, diffusion_coeff, batc
                            noise=None, use_graph=True, seed=None):
     """Euler-Maruyama reverse-SDE sampler (reference score_sampling.py:63-127).  Returns the last `mean_x`."""
     seed = _fresh_seed() if seed is None else seed
-    if isinstance(score_model, ScoreNet) and not _cfg_enabled(cfg):
+    if isinstance(score_model, ScoreNet) and not (_cfg_enabled(cfg) and score_model.training):
         return _native_run(N.SAMPLER_EM, score_model, batch_size, num_steps, 0.0, eps, img_size, y, cond_img, lsm_cond,
-                           topo_cond, noise, use_graph, seed, device)
+                           topo_cond, noise, use_graph, seed, device, cfg)
     lib, st = N.lib(), N.stream
     noise = iter(noise) if noise is not None else None
     ones = torch.ones(batch_size, device=device)
@@ -136,9 +149,9 @@ def pc_sampler(score_model, marginal_prob_std, diffusion_coeff, batch_size=64, n
     """Predictor-corrector sampler: Langevin corrector with the batch-mean gradient norm, then an Euler-Maruyama
     predictor (reference score_sampling.py:136-230).  Returns the last `x_mean`."""
     seed = _fresh_seed() if seed is None else seed
-    if isinstance(score_model, ScoreNet) and not _cfg_enabled(cfg):
+    if isinstance(score_model, ScoreNet) and not (_cfg_enabled(cfg) and score_model.training):
         return _native_run(N.SAMPLER_PC, score_model, batch_size, num_steps, snr, eps, img_size, y, cond_img, lsm_cond,
-                           topo_cond, noise, use_graph, seed, device)
+                           topo_cond, noise, use_graph, seed, device, cfg)
     lib, st = N.lib(), N.stream
     noise = iter(noise) if noise is not None else None
     ones = torch.ones(batch_size, device=device)

@@ -114,6 +114,32 @@ def test_cfg_guided_score_matches_reference_golden(golden_dir):
     assert maxrel(got.cpu(), g["guided"]) <= TOL
 
 
+GUIDED = {"classifier_free_guidance": {"enabled": True, "guidance_scale": 2.5, "guidance_scale_max": 1.5}}
+
+
+def test_guided_samplers_match_reference_goldens(golden_dir):
+    """live classifier-free guidance in the native loop: conditional + unconditional rows evaluated as one 2B batch"""
+    import sbgm_danra_amd as S
+    _, net, _ = build_pair(5, 4)
+    net.eval()
+    g = gp = load_golden(os.path.join(golden_dir, "pc_cfg_b2_32_2steps.npz"))
+    kw = dict(y=g["y"].cuda(), cond_img=g["cond_img"].cuda(), lsm_cond=g["lsm_cond"].cuda(), topo_cond=g["topo_cond"].cuda(),
+              cfg=GUIDED, device="cuda", batch_size=2, img_size=32)
+    got = S.pc_sampler(net, S.marginal_prob_std_fn, S.diffusion_coeff_fn, num_steps=2, noise=g["noise"], **kw)
+    assert maxrel(got.cpu(), g["x_mean"]) <= 1e-3
+    g = load_golden(os.path.join(golden_dir, "em_cfg_b2_32_3steps.npz"))
+    got = S.Euler_Maruyama_sampler(net, S.marginal_prob_std_fn, S.diffusion_coeff_fn, num_steps=3, noise=g["noise"], **kw)
+    assert maxrel(got.cpu(), g["mean_x"]) <= 1e-3
+    # graph replay == eager launches, and the generic-callable Python loop (two evaluations + combine kernel) agrees
+    a = S.pc_sampler(net, S.marginal_prob_std_fn, S.diffusion_coeff_fn, num_steps=3, seed=11, use_graph=True, **kw)
+    b = S.pc_sampler(net, S.marginal_prob_std_fn, S.diffusion_coeff_fn, num_steps=3, seed=11, use_graph=False, **kw)
+    assert torch.equal(a, b) and torch.isfinite(a).all()
+    f = lambda x, t, y=None, c=None, l=None, tp=None: net(x, t, y, c, l, tp)  # noqa: E731
+    c = S.pc_sampler(f, S.marginal_prob_std_fn, S.diffusion_coeff_fn, num_steps=2, noise=gp["noise"], **kw)
+    d = S.pc_sampler(net, S.marginal_prob_std_fn, S.diffusion_coeff_fn, num_steps=2, noise=gp["noise"], **kw)
+    assert maxrel(c.cpu(), d.cpu()) <= 1e-4
+
+
 def test_python_loop_sampler_equals_native_loop():
     """generic-callable path (Python loop + fused update kernels) vs the single-call native loop, same noise"""
     import sbgm_danra_amd as S
@@ -181,6 +207,29 @@ def test_full_size_properties_b32_128():
     assert torch.isfinite(full).all()
     assert maxrel(full[5:7].cpu(), solo.cpu()) <= 2e-5          # tile/split choices differ with B; values must not
     assert maxrel(full[5:6].cpu(), want) <= TOL
+
+
+def test_config4_256_pc_b16():
+    """BASELINE config 4 shape (256x256, attention over 1024 / 256 / 64 tokens, predictor-corrector, batch 16):
+    one sample against the oracle, then the full batch through size-independent properties (per-sample independence,
+    graph replay == eager launches bit for bit, finite output)."""
+    import sbgm_danra_amd as S
+    ora, net, _ = build_pair(1)
+    net.eval()
+    g = torch.Generator().manual_seed(256)
+    x, c = torch.randn(16, 1, 256, 256, generator=g).cuda(), torch.randn(16, 1, 256, 256, generator=g).cuda()
+    t = (torch.rand(16, generator=g) * 0.999 + 1e-3).cuda()
+    with torch.no_grad():
+        full = net(x, t, cond_img=c)
+        solo = net(x[3:4], t[3:4], cond_img=c[3:4])
+        want = ora.eval()(x[3:4].cpu(), t[3:4].cpu(), cond_img=c[3:4].cpu())
+    assert torch.isfinite(full).all()
+    assert maxrel(solo.cpu(), want) <= TOL
+    assert maxrel(full[3:4].cpu(), solo.cpu()) <= 2e-5
+    kw = dict(batch_size=16, num_steps=2, device="cuda", img_size=256, cond_img=c, seed=5)
+    a = S.pc_sampler(net, S.marginal_prob_std_fn, S.diffusion_coeff_fn, use_graph=True, **kw)
+    b = S.pc_sampler(net, S.marginal_prob_std_fn, S.diffusion_coeff_fn, use_graph=False, **kw)
+    assert torch.equal(a, b) and torch.isfinite(a).all() and a.shape == (16, 1, 256, 256)
 
 
 def test_errors_are_loud():
