@@ -241,6 +241,20 @@ int sbgm_langevin_step(float* x, const float* score, const float* z, float snr_n
 int sbgm_cfg_combine(float* out, const float* s_cond, const float* s_uncond, float scale, int64_t n, void* stream);
 int sbgm_randn_scaled(float* x, float scale, uint64_t seed, uint64_t draw_index, int64_t n, void* stream);
 
+/* ---- after the sampler -------------------------------------------------------------------------
+ * sbgm_pointwise_chain: y[i] = program(x[i]); the program is at most SBGM_CHAIN_MAX_OPS scalar steps, each rounded to fp32
+ * on its own exactly like the reference's tensor-scalar arithmetic.  Replaces the __call__ bodies of Scale /
+ * ScaleBackTransform (special_transforms.py:87-100, :125-139), ZScoreTransform / ZScoreBackTransform (:159-184, :202-233),
+ * PrcpLogTransform / PrcpLogBackTransform (:288-355, :418-462) and the generation clamp (training.py:744-748).
+ * x == y (in place) is allowed. */
+enum { SBGM_OP_ADD = 0, SBGM_OP_MUL = 1, SBGM_OP_DIV = 2, SBGM_OP_CLAMP_MIN = 3, SBGM_OP_CLAMP_MAX = 4, SBGM_OP_EXP = 5,
+       SBGM_OP_LOG = 6 };
+#define SBGM_CHAIN_MAX_OPS 12
+int sbgm_pointwise_chain(const float* x, float* y, int64_t n, int n_ops, const int* ops, const float* consts, void* stream);
+/* Per-sample maximum and q-quantile (torch.quantile "linear" interpolation, NaN-propagating) of x[B][per_sample]:
+ * the two statistics report_precip_extremes needs (utils.py:1647-1649).  out_max, out_q: device [B]. */
+int sbgm_sample_extremes(const float* x, int B, int64_t per_sample, float q, float* out_max, float* out_q, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

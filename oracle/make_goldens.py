@@ -228,6 +228,36 @@ noise = [torch.randn(2, 1, 32, 32) for _ in range(4)]
 np.savez_compressed(os.path.join(GOLD, "em_cfg_b2_32_3steps.npz"),
                     **npz({**{k: inp[k] for k in ("y", "cond_img", "lsm_cond", "topo_cond")}, "noise": torch.stack(noise), "mean_x": xr}))
 
+# ---- transforms / back-transforms: reference sbgm/special_transforms.py, imported as is --------------
+import sbgm.special_transforms as RT                                     # noqa: E402
+from oracle import transforms_ref as OT                                  # noqa: E402
+assert RT.__file__.startswith(REF)
+tg = torch.Generator().manual_seed(1234)
+z = torch.randn(3, 1, 24, 20, generator=tg) * 1.7                       # model-space field (z-scored / scaled)
+phys = torch.rand(3, 1, 24, 20, generator=tg) ** 4 * 80.0               # physical precipitation-like field, >= 0
+LOGP = dict(glob_mean_log=-1.2345, glob_std_log=2.0321, glob_min_log=-4.60517, glob_max_log=5.7038, buffer_frac=0.5)
+TR_CASES = {
+    "zscore_back": (lambda M: M.ZScoreBackTransform(8.7012, 6.1923), z),
+    "zscore_fwd": (lambda M: M.ZScoreTransform(8.7012, 6.1923), phys),
+    "scale_back": (lambda M: M.ScaleBackTransform(0, 1, -23.5, 41.25), z),
+    "scale_back_m11": (lambda M: M.ScaleBackTransform(-1, 1, 0.0, 155.3), z),
+    "scale_fwd": (lambda M: M.Scale(-1, 1, -23.5, 41.25), phys),
+    "log_fwd": (lambda M: M.PrcpLogTransform(scale_type="log", **LOGP), phys),
+    "log_back": (lambda M: M.PrcpLogBackTransform(scale_type="log", clamp_log_max=3.0, **LOGP), z),
+}
+for st in ("log_zscore", "log_01", "log_minus1_1"):
+    TR_CASES[st + "_fwd"] = (lambda M, st=st: M.PrcpLogTransform(scale_type=st, **LOGP), phys)
+    TR_CASES[st + "_back"] = (lambda M, st=st: M.PrcpLogBackTransform(scale_type=st, **LOGP), z)
+    TR_CASES[st + "_back_clamped"] = (lambda M, st=st: M.PrcpLogBackTransform(scale_type=st, clamp_log_min=-4.60517,
+                                                                             clamp_log_max=5.7038, **LOGP), z * 3)
+tr_out = {"z": z, "phys": phys}
+for name, (mk, inp_t) in TR_CASES.items():
+    a, b_ = mk(RT)(inp_t.clone()), mk(OT)(inp_t.clone())
+    report["transform/" + name] = maxrel(b_, a)
+    assert torch.equal(a, b_), name                                      # bit-identical on the same CPU
+    tr_out[name] = a
+np.savez_compressed(os.path.join(GOLD, "transforms.npz"), **npz(tr_out))
+
 with open(os.path.join(GOLD, "state_manifest.json"), "w") as f:
     json.dump(state_manifest, f, indent=0, sort_keys=True)
 with open(os.path.join(GOLD, "oracle_vs_reference.json"), "w") as f:

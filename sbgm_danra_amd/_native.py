@@ -61,6 +61,8 @@ SIGNATURES = {
     "sbgm_model_check_complete": (_i, [_vp]),
     "sbgm_model_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp), _i, _i, _i, _i, _vp]),
     "sbgm_sampler_run": (_i, [_vp, C.POINTER(SamplerArgs), _vp]),
+    "sbgm_pointwise_chain": (_i, [_vp, _vp, _i64, _i, C.POINTER(C.c_int), C.POINTER(C.c_float), _vp]),
+    "sbgm_sample_extremes": (_i, [_vp, _i, _i64, _f, _vp, _vp, _vp]),
     "sbgm_model_autotune": (_i, [_vp, _i, _i, _i, _vp]),
     "sbgm_model_tune_save": (_i, [_vp, C.c_char_p]),
     "sbgm_model_tune_load": (_i, [_vp, C.c_char_p]),

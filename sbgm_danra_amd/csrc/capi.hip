@@ -100,6 +100,15 @@ int sbgm_conv3x3_cout1_fwd(const float* x, const float* w_tap_c, const float* bi
 }
 int sbgm_act_inplace(float* x, int64_t n, int act, void* stream) { return sbgm_launch_act(x, (size_t)n, act, ST); }
 
+int sbgm_pointwise_chain(const float* x, float* y, int64_t n, int n_ops, const int* ops, const float* consts, void* stream) {
+    SBGM_CHECK(n >= 0 && (n_ops == 0 || (ops && consts)), "pointwise_chain: bad arguments");
+    return sbgm_launch_pointwise_chain(x, y, (size_t)n, n_ops, ops, consts, ST);
+}
+int sbgm_sample_extremes(const float* x, int B, int64_t per_sample, float q, float* out_max, float* out_q, void* stream) {
+    SBGM_CHECK(x && out_max && out_q && per_sample > 0, "sample_extremes: bad arguments");
+    return sbgm_launch_sample_extremes(x, B, (size_t)per_sample, q, out_max, out_q, ST);
+}
+
 // ---- training path: backward entry points ---------------------------------------------------------------------------
 int sbgm_conv_pack_weight_dgrad(const float* w_oihw, float* packed, int Cout, int Cin, int KH, int KW, void* stream) {
     // operator of the data gradient: Cout' = Cin, Cin' = Cout (padded to 16), taps flipped

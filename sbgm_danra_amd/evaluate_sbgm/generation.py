@@ -22,6 +22,13 @@ from ..utils import extract_samples, get_model_string
 logger = logging.getLogger(__name__)
 
 
+def maybe_inverse_transform(k, arr, back_transforms):
+    """reference generation.py:26-35"""
+    if back_transforms and k in back_transforms:
+        return back_transforms[k](arr)
+    return arr
+
+
 class SampleGenerator:
     def __init__(self, cfg, model, dataloader, back_transforms, device, literal_reference_bn: bool = False):
         self.cfg, self.model, self.dataloader, self.back_transforms, self.device = cfg, model, dataloader, back_transforms, device
@@ -31,18 +38,50 @@ class SampleGenerator:
         self.sample_path = os.path.join(self.output_dir, "generated_samples")
         os.makedirs(self.sample_path, exist_ok=True)
 
-    def _run_sampler(self, batch_size, y, cond_img, lsm_cond, topo_cond):
+    def _sample_device(self, batch_size, y, cond_img, lsm_cond, topo_cond):
+        """the sampler output as [B,H,W] still on the device (what _run_sampler returns after .cpu())"""
         gen = pc_sampler(score_model=self.model, marginal_prob_std=marginal_prob_std_fn, diffusion_coeff=diffusion_coeff_fn,
                          batch_size=batch_size, num_steps=self.cfg["sampler"]["n_timesteps"], device=self.device,
                          img_size=self.cfg["highres"]["data_size"][0], y=y, cond_img=cond_img, lsm_cond=lsm_cond,
                          topo_cond=topo_cond)
-        gen = gen.squeeze().detach().cpu()
+        gen = gen.squeeze().detach()
         if gen.ndim == 4:
             gen = gen.squeeze(1)
         elif gen.ndim == 2:
             gen = gen.unsqueeze(0)
         elif gen.ndim != 3:
             raise ValueError(f"Unknown generated sample shape: {gen.shape}")
+        return gen
+
+    def _run_sampler(self, batch_size, y, cond_img, lsm_cond, topo_cond):
+        """reference generation.py:56-83: [B,H,W] on the host"""
+        return self._sample_device(batch_size, y, cond_img, lsm_cond, topo_cond).cpu()
+
+    def _apply_backtransforms(self, x, generated, cond_images, seasons=None):
+        """reference generation.py:85-107, on the device: the transforms are elementwise, so one launch per key covers the
+        whole batch (the reference loops over samples and stacks).  cond_images comes back as the reference's nested list
+        [sample][variable] of [H,W] tensors."""
+        hr_key = self.cfg["highres"]["variable"] + "_hr"
+        if generated.ndim == 2:
+            generated = generated.unsqueeze(0)
+        x = maybe_inverse_transform(hr_key, x, self.back_transforms)
+        generated = maybe_inverse_transform(hr_key, generated, self.back_transforms)
+        if cond_images is not None:
+            keys = self.cfg["lowres"]["condition_variables"] or []
+            per_var = [maybe_inverse_transform(k + "_lr", cond_images[:, i], self.back_transforms) for i, k in enumerate(keys)]
+            cond_images = [[v[b] for v in per_var] for b in range(cond_images.shape[0])]
+        return x, generated, cond_images
+
+    def _generate(self, x, seasons, cond, lsm, topo, suffix, batch=None):
+        gen = self._sample_device(x.shape[0] if batch is None else batch, seasons, cond, lsm, topo)
+        cond_out = cond
+        if self.cfg["evaluation"].get("transform_back", False):
+            x, gen, cond_out = self._apply_backtransforms(x, gen, cond, seasons)
+        gen = gen.cpu()
+        self._save_npz({"gen_samples": gen, "eval_samples": x, "lsm_samples": lsm, "seasons": seasons}, suffix)
+        if cond_out is not None and isinstance(cond_out, list):
+            for i, k in enumerate(self.cfg["lowres"]["condition_variables"] or []):
+                self._save_npz({f"cond_samples_{k}": torch.stack([im[i] for im in cond_out])}, suffix)
         return gen
 
     def _save_npz(self, data, suffix):
@@ -58,15 +97,11 @@ class SampleGenerator:
 
     def generate_multiple(self):
         x, seasons, cond, lsm, topo = self._batch()
-        gen = self._run_sampler(x.shape[0], seasons, cond, lsm, topo)
-        self._save_npz({"gen_samples": gen, "eval_samples": x, "lsm_samples": lsm, "seasons": seasons}, f"multi_n_{x.shape[0]}")
-        return gen
+        return self._generate(x, seasons, cond, lsm, topo, f"multi_n_{x.shape[0]}")
 
     def generate_single(self):
         x, seasons, cond, lsm, topo = self._batch(first_only=True)
-        gen = self._run_sampler(1, seasons, cond, lsm, topo)
-        self._save_npz({"gen_samples": gen, "eval_samples": x, "lsm_samples": lsm, "seasons": seasons}, "single")
-        return gen
+        return self._generate(x, seasons, cond, lsm, topo, "single")
 
     def generate_repeated(self):
         """cfg.evaluation.n_repeats samples from ONE conditioning sample, drawn as one batch (independent noise per
@@ -76,8 +111,7 @@ class SampleGenerator:
         rank, world = parallel.world()
         mine = len(parallel.shard_range(n, rank, world))
         rep = lambda t: None if t is None else t.repeat(mine, *([1] * (t.dim() - 1)))   # noqa: E731
-        gen = self._run_sampler(mine, rep(seasons), rep(cond), rep(lsm), rep(topo)) if mine else None
-        if gen is not None:
-            self._save_npz({"gen_samples": gen, "eval_samples": x, "lsm_samples": lsm, "seasons": seasons},
-                           f"repeated_n_{n}" + (f"_rank{rank}" if world > 1 else ""))
-        return gen
+        if not mine:
+            return None
+        return self._generate(x, rep(seasons), rep(cond), rep(lsm), rep(topo),
+                              f"repeated_n_{n}" + (f"_rank{rank}" if world > 1 else ""), batch=mine)

@@ -13,7 +13,7 @@ from ..utils import get_model_string
 from .generation import SampleGenerator
 
 
-def generation_main(cfg, dataloader=None):
+def generation_main(cfg, dataloader=None, back_transforms=None):
     seed = cfg["evaluation"]["seed"]
     torch.manual_seed(seed)
     torch.cuda.manual_seed(seed)
@@ -28,7 +28,11 @@ def generation_main(cfg, dataloader=None):
     state = torch.load(os.path.join(ckpt_dir, ckpt_name), map_location=device, weights_only=True)["network_params"]
     model.load_state_dict(state)
     log.info(f"[INFO] Model checkpoint loaded from: {ckpt_dir}/{ckpt_name}")
-    gen = SampleGenerator(cfg, model, dataloader if dataloader is not None else get_gen_dataloader(cfg), None, device)
+    if back_transforms is None and cfg["evaluation"].get("transform_back", False):
+        # reference generation_main.py:93-108: inverse transforms from the saved global statistics (device-side classes)
+        from ..training import TrainingPipeline_general
+        back_transforms = TrainingPipeline_general._build_back_transforms(cfg)
+    gen = SampleGenerator(cfg, model, dataloader if dataloader is not None else get_gen_dataloader(cfg), back_transforms, device)
     out = {}
     for kind in cfg["evaluation"]["gen_type"]:
         if kind not in ("multiple", "single", "repeated"):

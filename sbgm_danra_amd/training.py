@@ -36,10 +36,15 @@ class TrainingPipeline_general:
         self.sdf_weighted_loss, self.with_ema = t.get("sdf_weighted_loss", False), t.get("with_ema", False)
         if self.weight_init:
             self.model.apply(self.custom_weight_initializer or self.xavier_init_weights)
-        mon = (cfg.get("monitoring", {}) or {}).get("extreme_prcp", {}) or {}
-        self.extreme_enabled = bool(mon.get("enabled", False))
+        mon = (cfg.get("monitoring", {}) or {}).get("extreme_prcp", {}) or {}      # training.py:151-160 (same defaults)
+        self.extreme_enabled = bool(mon.get("enabled", True))
         self.extreme_every_step = int(mon.get("every_steps", 50))
         self.extreme_threshold_mm = float(mon.get("threshold_mm", 500.0))
+        self.extreme_back_transform = bool(mon.get("back_transform", True))
+        self.extreme_log_first_n = int(mon.get("log_first_n", 5))
+        self.extreme_clamp_in_gen = bool(mon.get("clamp_in_generation", True))
+        self.back_transforms = self._build_back_transforms(cfg)        # device-side transforms; None when no stats are reachable
+        self.last_generation_check = None
         self.model_string = get_model_string(cfg)
         self.checkpoint_dir = cfg["paths"]["checkpoint_dir"]
         self.checkpoint_name = self.model_string + ".pth.tar"
@@ -48,6 +53,26 @@ class TrainingPipeline_general:
         for d in (self.checkpoint_dir, self.path_losses):
             os.makedirs(d, exist_ok=True)
         self._bucket = None
+
+    @staticmethod
+    def _build_back_transforms(cfg):
+        """training.py:162-185: inverse transforms from the saved global statistics, or None (the sentinel then runs on
+        model-space values, as in the reference when the stats cannot be loaded)."""
+        from .special_transforms import build_back_transforms_from_stats
+        try:
+            hr, lr = cfg["highres"], cfg["lowres"]
+            dims = lambda d: f"{d[0]}x{d[1]}" if d is not None else "full_domain"                 # noqa: E731
+            crop = lambda c: "_".join(map(str, c)) if c is not None else "no_crop"               # noqa: E731
+            return build_back_transforms_from_stats(
+                hr_var=hr["variable"], hr_model=hr["model"], domain_str_hr=dims(hr.get("full_domain_dims")),
+                crop_region_str_hr=crop(hr.get("cutout_domains")), hr_scaling_method=hr["scaling_method"],
+                hr_buffer_frac=hr.get("buffer_frac", 0.0), lr_vars=lr["condition_variables"], lr_model=lr["model"],
+                lr_scaling_methods=lr["scaling_methods"], domain_str_lr=dims(lr.get("full_domain_dims")),
+                crop_region_str_lr=crop(lr.get("cutout_domains")), lr_buffer_frac=lr.get("buffer_frac", 0.0), split="all",
+                stats_dir_root=cfg["paths"]["stats_load_dir"])
+        except Exception as e:                       # noqa: BLE001  (the reference swallows this too, :186-187)
+            logger.warning(f"[monitor] Could not build back transforms for sentinel; will skip back_transform in training. Error: {e}")
+            return None
 
     @staticmethod
     def xavier_init_weights(m):
@@ -81,7 +106,7 @@ class TrainingPipeline_general:
             self.optimizer.zero_grad()
             x, batch_loss = self._loss(samples)
             if self.extreme_enabled and idx % self.extreme_every_step == 0:
-                report_precip_extremes(x.detach().cpu(), "ground_truth_hr", self.extreme_threshold_mm, logger=logger.warning)
+                self._check_ground_truth(x)
             batch_loss.backward()
             if self._bucket is not None:
                 self._bucket.all_reduce_()            # the one collective of the path
@@ -139,8 +164,36 @@ class TrainingPipeline_general:
         if sampler is not ode_sampler:
             kw.update(y=seasons, cond_img=cond, lsm_cond=lsm, topo_cond=topo)
         gen = sampler(**kw)
-        mon = (cfg.get("monitoring", {}) or {}).get("extreme_prcp", {}) or {}
-        if mon.get("enabled"):
-            report_precip_extremes(gen.detach().cpu(), f"generated_epoch_{epoch}", float(mon.get("threshold_mm", 500.0)),
-                                   logger=logger.warning)
+        gen, self.last_generation_check = self.monitor_generated(gen, cfg)
         return gen
+
+    def _check_ground_truth(self, x):
+        """training.py:364-395: back-transform the HR batch (when configured) and run the sentinel, on the device"""
+        x_bt = x.detach()
+        bt = (self.back_transforms or {}).get("hr") if self.extreme_back_transform else None
+        if callable(bt):
+            x_bt = bt(x_bt)
+        return report_precip_extremes(x_bt, "ground_truth_hr", self.extreme_threshold_mm, logger=logger.warning)
+
+    def monitor_generated(self, gen, cfg):
+        """Post-sampler block of the reference's preview (training.py:697-748) without the host round trip:
+        back-transform -> sentinel -> optional clamp to [0, clamp_max_mm], all on the device; when the clamp fires it is
+        fused with the back-transform into one pass over the raw samples.  Returns (tensor to plot/save, sentinel dict)."""
+        mon = (cfg.get("monitoring", {}) or {}).get("extreme_prcp", {}) or {}
+        if not mon.get("enabled", self.extreme_enabled):
+            return gen, {"has_extreme": False}
+        from .special_transforms import _Chain, apply_chain, clamp_program, fuse
+        bt = (self.back_transforms or {}).get("hr") if mon.get("back_transform", True) else None
+        gen_bt = bt(gen) if callable(bt) else gen
+        thr = float(mon.get("threshold_mm", self.extreme_threshold_mm))
+        chk = report_precip_extremes(gen_bt.detach(), "generated_hr", cap_mm_day=thr, logger=logger.warning)
+        if chk.get("has_extreme", False):
+            vals = chk.get("extreme_values", [])
+            logger.warning("[monitor][gen] Extreme precipitation detected in generated samples:")
+            logger.warning(f"               max={max(vals):.1f} mm/day, count={len(vals)}, threshold={thr} mm/day")
+            if mon.get("clamp_in_generation", self.extreme_clamp_in_gen):
+                clamp_max = float(mon.get("clamp_max_mm", thr))
+                clamp = clamp_program(0.0, clamp_max)
+                gen = fuse(bt, clamp)(gen) if isinstance(bt, _Chain) else apply_chain(gen_bt, clamp)
+                logger.warning(f"[monitor][gen] Clamped generated samples to max {clamp_max} mm/day.")
+        return gen, chk

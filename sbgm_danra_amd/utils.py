@@ -44,20 +44,28 @@ def get_model_string(cfg) -> str:
 
 
 def report_precip_extremes(x_bt: torch.Tensor, name: str, cap_mm_day: float = 500.0, logger=print) -> dict:
-    """Per-sample sentinel on back-transformed precipitation: max above max(5 x p99.9, cap) or max below 0."""
-    flat = x_bt.flatten(1).float()
-    p999 = torch.quantile(flat, 0.999, dim=1).tolist()
-    mx = flat.max(dim=1).values.tolist()
-    ex = [m for p, m in zip(p999, mx) if m > max(5.0 * p, cap_mm_day)]
-    neg = [m for m in mx if m < 0]
-    for i, (p, m) in enumerate(zip(p999, mx)):
+    """Per-sample sentinel on back-transformed precipitation (reference utils.py:1642-1671): a sample is flagged when its
+    max exceeds max(5 x p99.9, cap) or is negative.  The two statistics (max, 99.9th percentile with torch.quantile's
+    linear interpolation) are computed on the device by `sbgm_sample_extremes`; only 2*B floats come back to the host.
+    Same messages and return dictionaries as the reference."""
+    from .special_transforms import sample_extremes
+    mx_t, p_t = sample_extremes(x_bt.flatten(1), 0.999)
+    stats = torch.stack([p_t, mx_t]).cpu()
+    n_ex, vals_ex, n_b0, vals_b0 = 0, [], 0, []
+    for i, (p, m) in enumerate(zip(stats[0].tolist(), stats[1].tolist())):
         if m > max(5.0 * p, cap_mm_day):
             logger(f"{name} sample {i} has extreme precipitation: max={m:.1f} mm/day > max(5xp99.9={p:.1f} mm/day)")
+            n_ex += 1
+            vals_ex.append(m)
         if m < 0:
             logger(f"{name} sample {i} has negative precipitation: max={m:.1f} mm/day < 0")
-    out = {"has_extreme": bool(ex)}
-    if ex:
-        out.update(n_extreme=len(ex), extreme_values=ex)
-    if neg:
-        out.update(has_below_zero=True, n_below_zero=len(neg), below_zero_values=neg)
-    return out
+            n_b0 += 1
+            vals_b0.append(m)
+    if n_b0 > 0 and n_ex > 0:
+        return {"has_extreme": True, "n_extreme": n_ex, "extreme_values": vals_ex, "has_below_zero": True,
+                "n_below_zero": n_b0, "below_zero_values": vals_b0}
+    if n_ex > 0:
+        return {"has_extreme": True, "n_extreme": n_ex, "extreme_values": vals_ex}
+    if n_b0 > 0:
+        return {"has_below_zero": True, "n_below_zero": n_b0, "below_zero_values": vals_b0}
+    return {"has_extreme": False}

@@ -96,3 +96,41 @@ def test_cli_train_one_epoch_then_generate(cfg_path):
     assert np.isfinite(np.load(os.path.join(out, "gen_samples_multi_n_3.npz"))["arr_0"]).all()
     losses = os.path.join(cfg.paths.path_save, "samples", get_model_string(cfg), "losses", f"losses_{get_model_string(cfg)}.pkl")
     assert os.path.exists(losses)
+
+
+def test_generation_back_transform_on_device(cfg_path, tmp_path):
+    """with evaluation.transform_back the saved samples are in physical units; the back-transform (built
+    from the saved global statistics like the reference's generation_main.py:93-108) runs on the device before the one
+    device->host copy.  Checked against the oracle's transform of the raw samples of an identical run."""
+    import json
+    import yaml as _yaml
+    from oracle import torch_ref as O
+    from oracle import transforms_ref as OT
+    from sbgm.evaluate_sbgm.generation_main import generation_main
+    from sbgm.utils import get_model_string, load_config
+    raw = _yaml.safe_load(open(cfg_path))
+    raw["evaluation"].update(gen_type=["multiple"], transform_back=True)
+    raw["lowres"]["scaling_methods"] = ["zscore", "log_zscore"]
+    p2 = tmp_path / "run_bt.yaml"
+    p2.write_text(_yaml.safe_dump(raw))
+    cfg = load_config(str(p2))
+    stats = dict(mean=281.5, std=9.25, min=0.0, max=120.0, log_mean=-1.1, log_std=1.9, log_min=-4.6, log_max=5.5)
+    for model, var in (("DANRA", "prcp"), ("ERA5", "temp"), ("ERA5", "prcp")):
+        d = os.path.join(cfg.paths.stats_load_dir, model, var, "all")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, f"global_stats__{model}__589x789__crop__170_350_340_520__{var}__all.json"), "w") as f:
+            json.dump(stats, f)
+    ora = O.build_scorenet(6, num_classes=4)
+    ckpt_dir = os.path.join(cfg.paths.path_save, cfg.paths.checkpoint_dir)
+    os.makedirs(ckpt_dir, exist_ok=True)
+    torch.save({"network_params": O.synth_state_dict(ora), "optimizer_params": {}}, os.path.join(ckpt_dir, get_model_string(cfg) + ".pth.tar"))
+    out = os.path.join(cfg.paths.sample_dir, "generation", get_model_string(cfg), "generated_samples")
+    bt = generation_main(cfg)["multiple"]
+    cond_t = np.load(os.path.join(out, "cond_samples_temp_multi_n_3.npz"))["arr_0"]
+    cfg.evaluation.transform_back = False
+    plain = generation_main(cfg)["multiple"]                                   # same seed -> same raw samples
+    want = OT.PrcpLogBackTransform(scale_type="log_zscore", glob_mean_log=-1.1, glob_std_log=1.9, glob_min_log=-4.6,
+                                   glob_max_log=5.5, buffer_frac=0.5, clamp_log_min=-4.6, clamp_log_max=5.5)(plain)
+    assert bt.shape == (3, 64, 64) and (bt > 0).all()
+    assert float(((bt - want).abs() / want.abs().clamp_min(1e-6)).max()) <= 2e-6
+    assert cond_t.shape == (3, 64, 64) and abs(float(cond_t.mean()) - 281.5) < 5.0      # z-scored N(0,1) field -> Kelvin-like
