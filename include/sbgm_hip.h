@@ -255,6 +255,29 @@ int sbgm_pointwise_chain(const float* x, float* y, int64_t n, int n_ops, const i
  * the two statistics report_precip_extremes needs (utils.py:1647-1649).  out_max, out_q: device [B]. */
 int sbgm_sample_extremes(const float* x, int B, int64_t per_sample, float q, float* out_max, float* out_q, void* stream);
 
+/* ---- before the network ------------------------------------------------------------------------
+ * Batch-level condition assembly: channel concatenation of the sorted *_lr fields (utils.py:441-447), classifier-free-
+ * guidance condition dropout (data_modules.py:957-983: LR fields -> 0, class label -> NULL token 0) and the value||mask
+ * layout of the geo fields (data_modules.py:971-993: mask 0 when dropped, 1 otherwise), one launch group per batch.
+ * All tensors NCHW fp32 on the device; dropped: uint8 [B] (NULL = nothing dropped); any input group may be NULL/absent. */
+#define SBGM_ASSEMBLE_MAX_LR 16
+typedef struct sbgm_assemble_args {
+    int B;
+    int64_t HW;                               /* H*W, a multiple of 4 */
+    int n_lr;                                 /* number of LR fields, already in sorted-key order */
+    const float* lr[SBGM_ASSEMBLE_MAX_LR];    /* each [B][lr_channels[k]][H][W] */
+    int lr_channels[SBGM_ASSEMBLE_MAX_LR];
+    const float* lsm;  int lsm_channels;      /* [B][1 or 2][H][W] */
+    const float* topo; int topo_channels;
+    const int64_t* y;                         /* [B] class labels */
+    const unsigned char* dropped;             /* [B] */
+    float* lr_out;                            /* [B][sum lr_channels][H][W] */
+    float* lsm_out;                           /* [B][2][H][W] */
+    float* topo_out;                          /* [B][2][H][W] */
+    int64_t* y_out;                           /* [B] */
+} sbgm_assemble_args;
+int sbgm_assemble_conditions(const sbgm_assemble_args* a, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

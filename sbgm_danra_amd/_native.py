@@ -34,6 +34,12 @@ class SamplerArgs(C.Structure):
                 ("cfg_scale_corrector", _f)]
 
 
+class AssembleArgs(C.Structure):
+    _fields_ = [("B", _i), ("HW", _i64), ("n_lr", _i), ("lr", _vp * 16), ("lr_channels", _i * 16), ("lsm", _vp),
+                ("lsm_channels", _i), ("topo", _vp), ("topo_channels", _i), ("y", _vp), ("dropped", _vp), ("lr_out", _vp),
+                ("lsm_out", _vp), ("topo_out", _vp), ("y_out", _vp)]
+
+
 class Profile(C.Structure):
     _fields_ = [("ms_total_with_events", _f), ("ms_conv", _f), ("ms_conv_max", _f), ("flops_conv", C.c_double),
                 ("flops_conv_max", C.c_double), ("n_conv", _i)]
@@ -63,6 +69,7 @@ SIGNATURES = {
     "sbgm_sampler_run": (_i, [_vp, C.POINTER(SamplerArgs), _vp]),
     "sbgm_pointwise_chain": (_i, [_vp, _vp, _i64, _i, C.POINTER(C.c_int), C.POINTER(C.c_float), _vp]),
     "sbgm_sample_extremes": (_i, [_vp, _i, _i64, _f, _vp, _vp, _vp]),
+    "sbgm_assemble_conditions": (_i, [C.POINTER(AssembleArgs), _vp]),
     "sbgm_model_autotune": (_i, [_vp, _i, _i, _i, _vp]),
     "sbgm_model_tune_save": (_i, [_vp, C.c_char_p]),
     "sbgm_model_tune_load": (_i, [_vp, C.c_char_p]),

@@ -109,6 +109,11 @@ int sbgm_sample_extremes(const float* x, int B, int64_t per_sample, float q, flo
     return sbgm_launch_sample_extremes(x, B, (size_t)per_sample, q, out_max, out_q, ST);
 }
 
+int sbgm_assemble_conditions(const sbgm_assemble_args* a, void* stream) {
+    SBGM_CHECK(a, "assemble_conditions: null args");
+    return sbgm_launch_assemble_conditions(*a, ST);
+}
+
 // ---- training path: backward entry points ---------------------------------------------------------------------------
 int sbgm_conv_pack_weight_dgrad(const float* w_oihw, float* packed, int Cout, int Cin, int KH, int KW, void* stream) {
     // operator of the data gradient: Cout' = Cin, Cin' = Cout (padded to 16), taps flipped

@@ -134,6 +134,10 @@ int sbgm_launch_langevin(float* x, const float* score, const float* z, float snr
                          size_t per_sample, hipStream_t st);
 int sbgm_launch_cfg_combine(float* out, const float* s_cond, const float* s_uncond, float scale, size_t n, hipStream_t st);
 
+// ---- batch_pack.hip (before the network) ------------------------------------------------------------------------------
+struct sbgm_assemble_args;
+int sbgm_launch_assemble_conditions(const sbgm_assemble_args& a, hipStream_t st);
+
 // ---- postproc.hip (after the sampler) ---------------------------------------------------------------------------------
 int sbgm_launch_pointwise_chain(const float* x, float* y, size_t n, int n_ops, const int* ops, const float* consts, hipStream_t st);
 int sbgm_launch_sample_extremes(const float* x, int B, size_t per, float q, float* out_max, float* out_q, hipStream_t st);

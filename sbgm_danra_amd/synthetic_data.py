@@ -9,7 +9,8 @@ from torch.utils.data import DataLoader, Dataset
 
 
 class SyntheticDownscalingDataset(Dataset):
-    def __init__(self, cfg, n_items: int = 64, seed: int = 42):
+    def __init__(self, cfg, n_items: int = 64, seed: int = 42, raw_geo: bool = False):
+        self.raw_geo = raw_geo       # True: 1-channel geo fields; the mask channel is then assembled on the device
         self.hw = tuple(cfg["highres"]["data_size"])
         self.hr_var = cfg["highres"]["variable"]
         self.lr_vars = list(cfg["lowres"]["condition_variables"] or [])
@@ -38,9 +39,13 @@ class SyntheticDownscalingDataset(Dataset):
             item["sdf"] = torch.rand(1, h, w, generator=g)
         if self.n_seasons:
             item["classifier"] = torch.randint(1, self.n_seasons + 1, (), generator=g)
+        if self.raw_geo:
+            for k in ("lsm", "topo"):
+                if k in item:
+                    item[k] = item[k][:1]
         return item
 
 
-def synthetic_loader(cfg, batch_size, n_items=None, seed=42, shuffle=False) -> DataLoader:
+def synthetic_loader(cfg, batch_size, n_items=None, seed=42, shuffle=False, raw_geo=False) -> DataLoader:
     n_items = n_items or 4 * batch_size
-    return DataLoader(SyntheticDownscalingDataset(cfg, n_items, seed), batch_size=batch_size, shuffle=shuffle, num_workers=0)
+    return DataLoader(SyntheticDownscalingDataset(cfg, n_items, seed, raw_geo), batch_size=batch_size, shuffle=shuffle, num_workers=0)

@@ -19,7 +19,8 @@ import torch.nn as nn
 
 from . import parallel
 from .score_sampling import Euler_Maruyama_sampler, ode_sampler, pc_sampler
-from .utils import extract_samples, get_model_string, report_precip_extremes
+from .utils import (draw_condition_dropout, extract_samples, extract_samples_device, get_model_string,
+                    report_precip_extremes)
 
 logger = logging.getLogger(__name__)
 _SAMPLERS = {"pc_sampler": pc_sampler, "Euler_Maruyama_sampler": Euler_Maruyama_sampler, "ode_sampler": ode_sampler}
@@ -90,8 +91,19 @@ class TrainingPipeline_general:
         return torch.save({"network_params": self.model.state_dict(), "optimizer_params": self.optimizer.state_dict()},
                           os.path.join(dirname, filename))
 
-    def _loss(self, samples):
-        x, seasons, cond, _lsm_hr, lsm, sdf, topo, _hp, _lp = extract_samples(samples, self.device)
+    def _extract(self, samples, split):
+        """Batch dict -> tensors on the device.  Raw batches (1-channel geo fields) and batches that need the
+        classifier-free-guidance condition dropout are assembled by the device-side packer (one launch group per batch,
+        reference data_modules.py:957-993); batches that already carry value||mask geo fields take the plain path."""
+        guidance = (self.cfg.get("classifier_free_guidance", {}) or {})
+        raw_geo = any(samples.get(k) is not None and samples[k].shape[1] == 1 for k in ("lsm", "topo"))
+        dropped = draw_condition_dropout(next(iter(samples.values())).shape[0], split, guidance)
+        if raw_geo or dropped is not None:
+            return extract_samples_device(samples, self.device, dropped)
+        return extract_samples(samples, self.device)
+
+    def _loss(self, samples, split="train"):
+        x, seasons, cond, _lsm_hr, lsm, sdf, topo, _hp, _lp = self._extract(samples, split)
         return x, self.loss_fn(self.model, x, self.marginal_prob_std_fn, y=seasons, cond_img=cond, lsm_cond=lsm,
                                topo_cond=topo, sdf_cond=sdf if self.sdf_weighted_loss else None)
 
@@ -122,7 +134,7 @@ class TrainingPipeline_general:
         loss_sum = 0.0
         with torch.inference_mode():
             for samples in dataloader:
-                loss_sum += self._loss(samples)[1].item()
+                loss_sum += self._loss(samples, "valid")[1].item()
         avg = loss_sum / max(1, len(dataloader))
         if verbose:
             logger.info(f"→ Validation Loss: {avg:.4f}")

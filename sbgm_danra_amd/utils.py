@@ -31,6 +31,63 @@ def extract_samples(samples: dict, device=None):
     return hr, cls, lr, img("lsm_hr"), img("lsm"), img("sdf"), img("topo"), pts[0], pts[1]
 
 
+def draw_condition_dropout(batch_size: int, split: str, guidance_cfg) -> torch.Tensor | None:
+    """Per-sample classifier-free-guidance dropout flags, drawn the way the reference dataset draws them: one
+    `torch.rand(())` per sample from the default CPU generator, training split only (data_modules.py:960-965).  The
+    threshold lookup is the reference's, including its quirk: `cfg.get(drop_prob, 0.1)` is keyed by the VALUE of drop_prob,
+    so the effective probability is 0.1 unless the dict holds such a key.  Returns uint8 [B] on the host, or None."""
+    g = guidance_cfg or {}
+    if split != "train" or not g.get("enabled", False):
+        return None
+    thr = g.get(g.get("drop_prob", 0.1), 0.1)
+    return torch.tensor([1 if float(torch.rand(())) < thr else 0 for _ in range(batch_size)], dtype=torch.uint8)
+
+
+def extract_samples_device(samples: dict, device, dropped: torch.Tensor | None = None):
+    """`extract_samples` for RAW batches (1-channel geo fields, separate *_lr fields), with the dataset-side condition
+    handling moved onto the device and batched: one `sbgm_assemble_conditions` call concatenates
+    the sorted *_lr fields, zeroes them / nulls the class label for dropped samples and writes the value||mask geo layout
+    (reference utils.py:441-447 + data_modules.py:957-993).  Same 9-tuple as `extract_samples`."""
+    import ctypes as C
+
+    from . import _native as N
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise N.NativeError(f"extract_samples_device assembles the batch on a ROCm device, got device={device!r}")
+
+    def img(k):
+        v = samples.get(k)
+        return None if v is None else N.f32c(v.to(dev, non_blocking=True))
+
+    hr_keys = [k for k in samples if k.endswith("_hr") and not k.endswith("_original") and k != "lsm_hr"]
+    if not hr_keys:
+        raise ValueError("No HR image found in samples dictionary.")
+    hr = img(hr_keys[0])
+    B, hw = hr.shape[0], hr.shape[-2] * hr.shape[-1]
+    lr_keys = sorted(k for k in samples if k.endswith("_lr") and not k.endswith("_original"))
+    lrs = [img(k) for k in lr_keys]
+    lsm, topo = img("lsm"), img("topo")
+    cls = samples.get("classifier")
+    cls = None if cls is None else cls.to(dev, non_blocking=True).to(torch.int64).contiguous()
+    drop_d = None if dropped is None else dropped.to(dev).to(torch.uint8).contiguous()
+    a = N.AssembleArgs()
+    a.B, a.HW, a.n_lr = B, hw, len(lrs)
+    for i, t in enumerate(lrs):
+        a.lr[i], a.lr_channels[i] = t.data_ptr(), t.shape[1]
+    c_lr = sum(t.shape[1] for t in lrs)
+    lr_out = torch.empty(B, c_lr, *hr.shape[-2:], device=dev) if lrs else None
+    lsm_out = None if lsm is None else torch.empty(B, 2, *hr.shape[-2:], device=dev)
+    topo_out = None if topo is None else torch.empty(B, 2, *hr.shape[-2:], device=dev)
+    y_out = None if cls is None else torch.empty_like(cls)
+    a.lsm, a.lsm_channels = N.ptr(lsm), 0 if lsm is None else lsm.shape[1]
+    a.topo, a.topo_channels = N.ptr(topo), 0 if topo is None else topo.shape[1]
+    a.y, a.dropped = N.ptr(cls), N.ptr(drop_d)
+    a.lr_out, a.lsm_out, a.topo_out, a.y_out = N.ptr(lr_out), N.ptr(lsm_out), N.ptr(topo_out), N.ptr(y_out)
+    N.check(N.lib().sbgm_assemble_conditions(C.byref(a), N.stream()))
+    pts = [None if samples.get(k) is None else samples[k].to(dev).float() for k in ("hr_point", "lr_point")]
+    return hr, y_out, lr_out, img("lsm_hr"), lsm_out, img("sdf"), topo_out, pts[0], pts[1]
+
+
 def get_model_string(cfg) -> str:
     """Checkpoint / output naming scheme of the reference (utils.py:88-128)."""
     hr = tuple(cfg["highres"]["data_size"]) if cfg["highres"].get("data_size") is not None else (128, 128)

@@ -113,3 +113,52 @@ def test_monitor_block_back_transform_sentinel_clamp():
     # nothing extreme -> the raw samples come back untouched (the reference only replaces them when it clamps)
     out2, chk2 = p.monitor_generated(gen[:2].cuda(), mon)
     assert chk2 == {"has_extreme": False} and torch.equal(out2.cpu(), gen[:2])
+
+
+@pytest.mark.parametrize("B,hw,lr_channels,geo,labels,drop", [
+    (5, (32, 32), [1, 1, 1], (1, 1), True, [0, 1, 0, 1, 1]),
+    (3, (20, 12), [2, 1], (2, 1), True, None),                 # lsm already carries its mask channel: copied through
+    (3, (20, 12), [2, 1], (1, 1), True, [1, 0, 0]),            # a 2-channel LR field
+    (4, (16, 16), [1], (0, 1), False, None),                   # no dropout (validation split), no lsm, no labels
+    (2, (64, 64), [], (1, 0), True, [1, 1]),
+])
+def test_condition_assembly_matches_oracle(B, hw, lr_channels, geo, labels, drop):
+    """device batch assembly == the reference dataset's per-sample dropout / mask logic followed by
+    collation and extract_samples (oracle/data_ref.py), bit for bit."""
+    from oracle import data_ref as OD
+    from sbgm_danra_amd.utils import extract_samples_device
+    g = torch.Generator().manual_seed(B * 31 + hw[0])
+    names = ["temp", "prcp", "ewvf", "nwvf"]
+    items = []
+    for b in range(B):
+        it = {"prcp_hr": torch.randn(1, *hw, generator=g)}
+        for k, c in enumerate(lr_channels):
+            it[f"{names[k]}_lr"] = torch.randn(c, *hw, generator=g)
+        if geo[0]:
+            it["lsm"] = (torch.rand(geo[0], *hw, generator=g) > 0.5).float()
+        if geo[1]:
+            it["topo"] = torch.rand(geo[1], *hw, generator=g)
+        if labels:
+            it["classifier"] = torch.randint(1, 5, (), generator=g)
+        items.append(it)
+    raw = {k: torch.stack([it[k] for it in items]) for k in items[0]}
+    guidance = {"enabled": drop is not None}
+    done = [OD.finish_sample({k: v.clone() for k, v in it.items()}, "train", guidance, 0.0 if (drop and drop[b]) else 0.9)[0]
+            for b, it in enumerate(items)]
+    want = OD.extract_samples({k: torch.stack([d[k] for d in done]) for k in done[0]})
+    got = extract_samples_device(raw, "cuda", None if drop is None else torch.tensor(drop, dtype=torch.uint8))
+    for w, h in zip(want, got):
+        assert (w is None) == (h is None)
+        if w is not None:
+            assert w.shape == h.shape and torch.equal(w, h.cpu())
+
+
+def test_dropout_draw_follows_reference_rng_order():
+    from sbgm_danra_amd.utils import draw_condition_dropout
+    torch.manual_seed(123)
+    want = [1 if float(torch.rand(())) < 0.1 else 0 for _ in range(64)]
+    torch.manual_seed(123)
+    got = draw_condition_dropout(64, "train", {"enabled": True, "drop_prob": 0.5})     # the reference ignores drop_prob (:964)
+    assert got.tolist() == want and sum(want) > 0
+    assert draw_condition_dropout(8, "valid", {"enabled": True}) is None
+    assert draw_condition_dropout(8, "train", {"enabled": False}) is None
