@@ -99,6 +99,11 @@ typedef struct sbgm_sampler_args {
     int cfg_enabled;         /* classifier-free guidance on (cfg['classifier_free_guidance']['enabled']) */
     float cfg_scale;         /* guidance weight w of the predictor / Euler-Maruyama evaluation */
     float cfg_scale_corrector; /* w of the PC corrector evaluation (the reference clamps only this one to guidance_scale_max, :184-186) */
+    /* Full-domain tiling (optional): the B samples are tiles of one domain.  tile_origins: device int32 [B][2] = (y0, x0),
+     * x0 % 4 == 0; the in-kernel noise is then keyed by DOMAIN position, so overlapping tiles draw identical noise on the
+     * pixels they share.  NULL = independent samples. */
+    const int* tile_origins;
+    int domain_w;
 } sbgm_sampler_args;
 int sbgm_sampler_run(sbgm_model* m, const sbgm_sampler_args* a, void* stream);
 
@@ -277,6 +282,15 @@ typedef struct sbgm_assemble_args {
     int64_t* y_out;                           /* [B] */
 } sbgm_assemble_args;
 int sbgm_assemble_conditions(const sbgm_assemble_args* a, void* stream);
+
+/* ---- full-domain tiling (no reference counterpart, specification in DESIGN.md) -----------------
+ * origins: device int32 [T][2] = (y0, x0) of every tile; the host validates that each tile lies inside the domain.
+ * extract: tiles[T][C][th][tw] <- domain[C][Hd][Wd].   stitch: domain <- normalised blend of the covering tiles with
+ * linear ramps of `ramp_len` pixels on tile edges that are not domain edges. */
+int sbgm_extract_tiles(const float* domain, const int* origins, float* tiles, int T, int C, int Hd, int Wd, int th, int tw,
+                       void* stream);
+int sbgm_stitch_tiles(const float* tiles, const int* origins, float* domain, int T, int C, int Hd, int Wd, int th, int tw,
+                      int ramp_len, void* stream);
 
 #ifdef __cplusplus
 }

@@ -31,7 +31,7 @@ class SamplerArgs(C.Structure):
     _fields_ = [("kind", _i), ("B", _i), ("H", _i), ("W", _i), ("num_steps", _i), ("eps", _f), ("snr", _f),
                 ("seed", _u64), ("use_graph", _i), ("bn_train", _i), ("y", _vp), ("cond_img", _vp), ("lsm_cond", _vp),
                 ("topo_cond", _vp), ("noise", _vp), ("out", _vp), ("cfg_enabled", _i), ("cfg_scale", _f),
-                ("cfg_scale_corrector", _f)]
+                ("cfg_scale_corrector", _f), ("tile_origins", _vp), ("domain_w", _i)]
 
 
 class AssembleArgs(C.Structure):
@@ -70,6 +70,8 @@ SIGNATURES = {
     "sbgm_pointwise_chain": (_i, [_vp, _vp, _i64, _i, C.POINTER(C.c_int), C.POINTER(C.c_float), _vp]),
     "sbgm_sample_extremes": (_i, [_vp, _i, _i64, _f, _vp, _vp, _vp]),
     "sbgm_assemble_conditions": (_i, [C.POINTER(AssembleArgs), _vp]),
+    "sbgm_extract_tiles": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "sbgm_stitch_tiles": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "sbgm_model_autotune": (_i, [_vp, _i, _i, _i, _vp]),
     "sbgm_model_tune_save": (_i, [_vp, C.c_char_p]),
     "sbgm_model_tune_load": (_i, [_vp, C.c_char_p]),

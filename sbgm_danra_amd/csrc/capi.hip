@@ -114,6 +114,17 @@ int sbgm_assemble_conditions(const sbgm_assemble_args* a, void* stream) {
     return sbgm_launch_assemble_conditions(*a, ST);
 }
 
+int sbgm_extract_tiles(const float* domain, const int* origins, float* tiles, int T, int C, int Hd, int Wd, int th, int tw,
+                       void* stream) {
+    SBGM_CHECK(domain && origins && tiles, "extract_tiles: null pointer");
+    return sbgm_launch_extract_tiles(domain, origins, tiles, T, C, Hd, Wd, th, tw, ST);
+}
+int sbgm_stitch_tiles(const float* tiles, const int* origins, float* domain, int T, int C, int Hd, int Wd, int th, int tw,
+                      int ramp_len, void* stream) {
+    SBGM_CHECK(domain && origins && tiles, "stitch_tiles: null pointer");
+    return sbgm_launch_stitch_tiles(tiles, origins, domain, T, C, Hd, Wd, th, tw, ramp_len, ST);
+}
+
 // ---- training path: backward entry points ---------------------------------------------------------------------------
 int sbgm_conv_pack_weight_dgrad(const float* w_oihw, float* packed, int Cout, int Cin, int KH, int KW, void* stream) {
     // operator of the data gradient: Cout' = Cin, Cin' = Cout (padded to 16), taps flipped

@@ -763,7 +763,13 @@ int sbgm_model::sampler(const sbgm_sampler_args& a, hipStream_t caller) {
     const float* z = a.noise;
     size_t draw = 0;
     auto next_z = [&]() -> const float* { const float* p = z ? z + draw * n : nullptr; ++draw; return p; };
-    if (sbgm_launch_init_noise(xs, std1, next_z(), a.seed, d_state, 0, n, st)) return 1;
+    NoiseMap nm{};
+    if (a.tile_origins) {
+        SBGM_CHECK(W % 4 == 0 && a.domain_w >= W, "sampler: tiled noise needs W %% 4 == 0 and domain_w >= W (W=%d, domain_w=%d)", W,
+                   a.domain_w);
+        nm = NoiseMap{a.tile_origins, H, W / 4, (a.domain_w + 3) / 4};
+    }
+    if (sbgm_launch_init_noise(xs, std1, next_z(), a.seed, d_state, 0, n, st, nm)) return 1;
     if (sbgm_launch_fill_t(t_dev, tab[0].t, BE, st)) return 1;
     const float snr_nn = (float)((double)a.snr * std::sqrt((double)per));     // snr * sqrt(prod(x.shape[1:])) (:202-203)
 
@@ -776,11 +782,11 @@ int sbgm_model::sampler(const sbgm_sampler_args& a, hipStream_t caller) {
     auto one_step = [&](bool with_noise_ptrs) -> int {
         if (a.kind == SBGM_SAMPLER_PC) {
             if (evaluate(a.cfg_scale_corrector)) return 1;
-            if (sbgm_launch_langevin(xs, score, with_noise_ptrs ? next_z() : nullptr, snr_nn, sumsq, d_state, 0, a.seed, B, per, st)) return 1;
+            if (sbgm_launch_langevin(xs, score, with_noise_ptrs ? next_z() : nullptr, snr_nn, sumsq, d_state, 0, a.seed, B, per, st, nm)) return 1;
         }
         if (evaluate(a.cfg_scale)) return 1;
         return sbgm_launch_em_update(xs, xmean, score, with_noise_ptrs ? next_z() : nullptr, d_table, d_state, nullptr, 0, t_dev,
-                                     a.seed, B, per, N, st, BE);
+                                     a.seed, B, per, N, st, BE, nm);
     };
 
     const size_t saved_ws = ws_bytes;

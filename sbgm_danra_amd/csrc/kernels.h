@@ -120,23 +120,36 @@ struct SamplerState {      // device-resident, lets one captured graph serve eve
     unsigned long long step;        // advanced by the predictor kernel
     unsigned long long rng_offset;  // Philox counter base, advanced by every noise-drawing kernel
 };
+// optional map from tile-local quads to domain-global Philox counters (null origins = plain element order)
+struct NoiseMap {
+    const int* origins;   // device [B][2] = (y0, x0) of each tile in the domain, x0 % 4 == 0
+    int tile_h, tile_w4;  // tile rows, tile width / 4
+    int dom_w4;           // ceil(domain width / 4)
+};
 int sbgm_launch_fill_t(float* t, float value, int B, hipStream_t st);
 // `state` != null: scalars / RNG offset come from device memory (graph-replayable) and the state is advanced after
 // the update; `state` == null: explicit by-value scalars and draw index.
 int sbgm_launch_init_noise(float* x, float scale, const float* z, unsigned long long seed, SamplerState* state,
-                           unsigned long long draw_index, size_t n, hipStream_t st);
+                           unsigned long long draw_index, size_t n, hipStream_t st, NoiseMap nm = NoiseMap{});
 int sbgm_launch_em_update(float* x, float* x_mean, const float* score, const float* z, const StepScalars* table,
                           SamplerState* state, const StepScalars* sc_val, unsigned long long draw_index, float* t_dev,
                           unsigned long long seed, int B, size_t per_sample, int n_steps, hipStream_t st,
-                          int t_entries = 0);   // entries of t_dev to refresh (0 -> B; 2B for the batched guidance pass)
+                          int t_entries = 0,    // entries of t_dev to refresh (0 -> B; 2B for the batched guidance pass)
+                          NoiseMap nm = NoiseMap{});
 int sbgm_launch_langevin(float* x, const float* score, const float* z, float snr_noise_norm, double* sumsq_ws,
                          SamplerState* state, unsigned long long draw_index, unsigned long long seed, int B,
-                         size_t per_sample, hipStream_t st);
+                         size_t per_sample, hipStream_t st, NoiseMap nm = NoiseMap{});
 int sbgm_launch_cfg_combine(float* out, const float* s_cond, const float* s_uncond, float scale, size_t n, hipStream_t st);
 
 // ---- batch_pack.hip (before the network) ------------------------------------------------------------------------------
 struct sbgm_assemble_args;
 int sbgm_launch_assemble_conditions(const sbgm_assemble_args& a, hipStream_t st);
+
+// ---- tiling.hip (full-domain tiles) -----------------------------------------------------------------------------------
+int sbgm_launch_extract_tiles(const float* dom, const int* origins, float* tiles, int T, int C, int Hd, int Wd, int th, int tw,
+                              hipStream_t st);
+int sbgm_launch_stitch_tiles(const float* tiles, const int* origins, float* dom, int T, int C, int Hd, int Wd, int th, int tw,
+                             int ramp_len, hipStream_t st);
 
 // ---- postproc.hip (after the sampler) ---------------------------------------------------------------------------------
 int sbgm_launch_pointwise_chain(const float* x, float* y, size_t n, int n_ops, const int* ops, const float* consts, hipStream_t st);

@@ -44,6 +44,17 @@ __device__ __forceinline__ f32x4 philox_normal4(unsigned long long seed, unsigne
     return f32x4{r0 * c0, r0 * s0, r1 * c1, r1 * s1};
 }
 
+// Philox counter of quad i of a [B][H][W] batch.  Default: the quad index itself.  With a tile map (full-domain tiling,
+// SURVEY.md 8f rank 3) the counter is the quad's position in the DOMAIN, so pixels that several overlapping tiles share
+// receive the same draw in every tile and the tiles stay consistent where they are blended.
+__device__ __forceinline__ unsigned long long noise_index(const NoiseMap& m, size_t i) {
+    if (!m.origins) return i;
+    const size_t per4 = (size_t)m.tile_h * m.tile_w4;
+    const size_t b = i / per4, rem = i - b * per4;
+    const size_t y = rem / m.tile_w4, x4 = rem - y * m.tile_w4;
+    return ((unsigned long long)(m.origins[2 * b] + y)) * m.dom_w4 + (unsigned long long)(m.origins[2 * b + 1] >> 2) + x4;
+}
+
 __global__ void fill_kernel(float* t, float v, int n) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) t[i] = v;
@@ -52,10 +63,10 @@ __global__ void fill_kernel(float* t, float v, int n) {
 // x = scale * N(0,1)   (sampler start: randn * marginal_prob_std(1), score_sampling.py:94-95, :168)
 __global__ __launch_bounds__(256) void init_noise_kernel(float* __restrict__ x, float scale, const float* __restrict__ z,
                                                          unsigned long long seed, const SamplerState* __restrict__ state,
-                                                         unsigned long long off_val, size_t n4) {
+                                                         unsigned long long off_val, size_t n4, NoiseMap nm) {
     const unsigned long long off = state ? state->rng_offset : off_val;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        const f32x4 n = z ? reinterpret_cast<const f32x4*>(z)[i] : philox_normal4(seed, off, i);
+        const f32x4 n = z ? reinterpret_cast<const f32x4*>(z)[i] : philox_normal4(seed, off, noise_index(nm, i));
         reinterpret_cast<f32x4*>(x)[i] = n * scale;
     }
 }
@@ -65,13 +76,14 @@ __global__ __launch_bounds__(256) void em_update_kernel(float* __restrict__ x, f
                                                         const float* __restrict__ score, const float* __restrict__ z,
                                                         const StepScalars* __restrict__ table,
                                                         const SamplerState* __restrict__ state, StepScalars sc_val,
-                                                        unsigned long long off_val, unsigned long long seed, size_t n4) {
+                                                        unsigned long long off_val, unsigned long long seed, size_t n4,
+                                                        NoiseMap nm) {
     const StepScalars sc = state ? table[state->step] : sc_val;
     const unsigned long long off = state ? state->rng_offset : off_val;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
         const f32x4 sv = reinterpret_cast<const f32x4*>(score)[i];
-        const f32x4 n = z ? reinterpret_cast<const f32x4*>(z)[i] : philox_normal4(seed, off, i);
+        const f32x4 n = z ? reinterpret_cast<const f32x4*>(z)[i] : philox_normal4(seed, off, noise_index(nm, i));
         const f32x4 mean = xv + (sc.g2 * sv) * sc.dt;   // association of score_sampling.py:124/:224
         reinterpret_cast<f32x4*>(x_mean)[i] = mean;
         reinterpret_cast<f32x4*>(x)[i] = mean + sc.noise * n;
@@ -111,7 +123,7 @@ __global__ __launch_bounds__(256) void langevin_kernel(float* __restrict__ x, co
                                                        const double* __restrict__ sumsq,
                                                        const SamplerState* __restrict__ state,
                                                        unsigned long long off_val, unsigned long long seed, int B,
-                                                       size_t n4) {
+                                                       size_t n4, NoiseMap nm) {
     float gn = 0.f;
     for (int b = 0; b < B; ++b) gn += (float)sqrt(sumsq[b]);
     gn /= (float)B;
@@ -122,7 +134,7 @@ __global__ __launch_bounds__(256) void langevin_kernel(float* __restrict__ x, co
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
         const f32x4 sv = reinterpret_cast<const f32x4*>(score)[i];
-        const f32x4 n = z ? reinterpret_cast<const f32x4*>(z)[i] : philox_normal4(seed, off, i);
+        const f32x4 n = z ? reinterpret_cast<const f32x4*>(z)[i] : philox_normal4(seed, off, noise_index(nm, i));
         reinterpret_cast<f32x4*>(x)[i] = xv + eps * sv + nz * n;
     }
 }
@@ -146,10 +158,10 @@ int sbgm_launch_fill_t(float* t, float value, int B, hipStream_t st) {
 }
 
 int sbgm_launch_init_noise(float* x, float scale, const float* z, unsigned long long seed, SamplerState* state,
-                           unsigned long long draw_index, size_t n, hipStream_t st) {
+                           unsigned long long draw_index, size_t n, hipStream_t st, NoiseMap nm) {
     SBGM_CHECK(n % 4 == 0, "init_noise: element count must be a multiple of 4");
     hipLaunchKernelGGL(init_noise_kernel, dim3(stream_blocks(n / 4)), dim3(256), 0, st, x, scale, z, seed, state, draw_index,
-                       n / 4);
+                       n / 4, nm);
     SBGM_LAUNCH_CHECK();
     if (state) {
         hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(64), 0, st, state, (const StepScalars*)nullptr, (float*)nullptr, 0, 0, 0);
@@ -160,7 +172,8 @@ int sbgm_launch_init_noise(float* x, float scale, const float* z, unsigned long 
 
 int sbgm_launch_em_update(float* x, float* x_mean, const float* score, const float* z, const StepScalars* table,
                           SamplerState* state, const StepScalars* sc_val, unsigned long long draw_index, float* t_dev,
-                          unsigned long long seed, int B, size_t per_sample, int n_steps, hipStream_t st, int t_entries) {
+                          unsigned long long seed, int B, size_t per_sample, int n_steps, hipStream_t st, int t_entries,
+                          NoiseMap nm) {
     const size_t n = (size_t)B * per_sample;
     if (t_entries <= 0) t_entries = B;
     SBGM_CHECK(n % 4 == 0, "em_update: element count must be a multiple of 4");
@@ -168,7 +181,7 @@ int sbgm_launch_em_update(float* x, float* x_mean, const float* score, const flo
     SBGM_CHECK(state != nullptr || sc_val != nullptr, "em_update: need a device table or explicit scalars");
     const StepScalars v = sc_val ? *sc_val : StepScalars{};
     hipLaunchKernelGGL(em_update_kernel, dim3(stream_blocks(n / 4)), dim3(256), 0, st, x, x_mean, score, z, table, state, v,
-                       draw_index, seed, n / 4);
+                       draw_index, seed, n / 4, nm);
     SBGM_LAUNCH_CHECK();
     if (state) {
         hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(1024), 0, st, state, table, t_dev, t_entries, 1, n_steps);
@@ -179,7 +192,7 @@ int sbgm_launch_em_update(float* x, float* x_mean, const float* score, const flo
 
 int sbgm_launch_langevin(float* x, const float* score, const float* z, float snr_noise_norm, double* sumsq_ws,
                          SamplerState* state, unsigned long long draw_index, unsigned long long seed, int B,
-                         size_t per_sample, hipStream_t st) {
+                         size_t per_sample, hipStream_t st, NoiseMap nm) {
     SBGM_CHECK(per_sample % 4 == 0, "langevin: per-sample element count must be a multiple of 4");
     SBGM_HIP(hipMemsetAsync(sumsq_ws, 0, sizeof(double) * B, st));
     const int bx = (int)std::min<size_t>((per_sample / 4 + 255) / 256, 64);
@@ -187,7 +200,7 @@ int sbgm_launch_langevin(float* x, const float* score, const float* z, float snr
     SBGM_LAUNCH_CHECK();
     const size_t n4 = (size_t)B * per_sample / 4;
     hipLaunchKernelGGL(langevin_kernel, dim3(stream_blocks(n4)), dim3(256), 0, st, x, score, z, snr_noise_norm, sumsq_ws,
-                       state, draw_index, seed, B, n4);
+                       state, draw_index, seed, B, n4, nm);
     SBGM_LAUNCH_CHECK();
     if (state) {
         hipLaunchKernelGGL(advance_kernel, dim3(1), dim3(64), 0, st, state, (const StepScalars*)nullptr, (float*)nullptr, 0, 0, 0);

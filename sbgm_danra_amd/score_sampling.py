@@ -85,7 +85,7 @@ def _guidance(cfg):
 
 
 def _native_run(kind, score_model: ScoreNet, batch_size, num_steps, snr, eps, hw, y, cond_img, lsm_cond, topo_cond,
-                noise, use_graph, seed, device, cfg=None):
+                noise, use_graph, seed, device, cfg=None, tile_origins=None, domain_width=0):
     dev = torch.device(device) if not isinstance(device, torch.device) else device
     if dev.type != "cuda":
         raise N.NativeError(f"the native samplers run on a ROCm device, got device={device!r}")
@@ -103,7 +103,13 @@ def _native_run(kind, score_model: ScoreNet, batch_size, num_steps, snr, eps, hw
         nz = N.f32c(nz.to(dev))
     a = N.SamplerArgs(kind, batch_size, hw, hw, int(num_steps), float(eps), float(snr), int(seed), int(bool(use_graph)),
                       int(score_model.training), N.ptr(y), N.ptr(cond_img), N.ptr(lsm_cond), N.ptr(topo_cond), N.ptr(nz),
-                      out.data_ptr(), *_guidance(cfg))
+                      out.data_ptr(), *_guidance(cfg), N.ptr(tile_origins), int(domain_width or 0))
+    if tile_origins is not None:
+        N.require_device(tile_origins)
+        if tile_origins.dtype != torch.int32 or tuple(tile_origins.shape) != (batch_size, 2) or not tile_origins.is_contiguous():
+            raise ValueError("tile_origins must be a contiguous int32 [batch, 2] device tensor of (y0, x0)")
+        if noise is not None:
+            raise ValueError("tile_origins keys the in-kernel noise; it cannot be combined with injected noise")
     N.check(eng.lib.sbgm_sampler_run(eng.h, C.byref(a), N.stream()))
     if score_model.training:
         eng.download_bn_stats(score_model)
@@ -112,12 +118,14 @@ def _native_run(kind, score_model: ScoreNet, batch_size, num_steps, snr, eps, hw
 
 def Euler_Maruyama_sampler(score_model, marginal_prob_std, diffusion_coeff, batch_size=64, num_steps=500, device="cuda",
                            eps=1e-3, img_size=64, y=None, cond_img=None, lsm_cond=None, topo_cond=None, cfg=None, *,
-                           noise=None, use_graph=True, seed=None):
+                           noise=None, use_graph=True, seed=None, tile_origins=None, domain_width=0):
     """Euler-Maruyama reverse-SDE sampler (reference score_sampling.py:63-127).  Returns the last `mean_x`."""
     seed = _fresh_seed() if seed is None else seed
     if isinstance(score_model, ScoreNet) and not (_cfg_enabled(cfg) and score_model.training):
         return _native_run(N.SAMPLER_EM, score_model, batch_size, num_steps, 0.0, eps, img_size, y, cond_img, lsm_cond,
-                           topo_cond, noise, use_graph, seed, device, cfg)
+                           topo_cond, noise, use_graph, seed, device, cfg, tile_origins, domain_width)
+    if tile_origins is not None:
+        raise N.NativeError("domain-keyed noise (tile_origins) needs the native sampler loop (a ScoreNet in eval mode)")
     lib, st = N.lib(), N.stream
     noise = iter(noise) if noise is not None else None
     ones = torch.ones(batch_size, device=device)
@@ -145,13 +153,15 @@ def Euler_Maruyama_sampler(score_model, marginal_prob_std, diffusion_coeff, batc
 
 def pc_sampler(score_model, marginal_prob_std, diffusion_coeff, batch_size=64, num_steps=800, snr=signal_to_noise_ratio,
                device="cuda", eps=1e-3, img_size=64, y=None, cond_img=None, lsm_cond=None, topo_cond=None, cfg=None, *,
-               noise=None, use_graph=True, seed=None):
+               noise=None, use_graph=True, seed=None, tile_origins=None, domain_width=0):
     """Predictor-corrector sampler: Langevin corrector with the batch-mean gradient norm, then an Euler-Maruyama
     predictor (reference score_sampling.py:136-230).  Returns the last `x_mean`."""
     seed = _fresh_seed() if seed is None else seed
     if isinstance(score_model, ScoreNet) and not (_cfg_enabled(cfg) and score_model.training):
         return _native_run(N.SAMPLER_PC, score_model, batch_size, num_steps, snr, eps, img_size, y, cond_img, lsm_cond,
-                           topo_cond, noise, use_graph, seed, device, cfg)
+                           topo_cond, noise, use_graph, seed, device, cfg, tile_origins, domain_width)
+    if tile_origins is not None:
+        raise N.NativeError("domain-keyed noise (tile_origins) needs the native sampler loop (a ScoreNet in eval mode)")
     lib, st = N.lib(), N.stream
     noise = iter(noise) if noise is not None else None
     ones = torch.ones(batch_size, device=device)
