@@ -44,6 +44,8 @@ typedef struct sbgm_model_config {
     int gn_groups;           /* cfg.model.decoder_gn_groups */
     int decoder_activation;  /* SBGM_RELU / SBGM_SILU / SBGM_GELU (cfg.model.decoder_activation) */
     float sigma;             /* VE-SDE sigma (25.0, score_unet.py:932) */
+    int decoder_transpose;   /* 0: bilinear x2 + conv_up (default); 1: ConvTranspose2d(k=2, s=2) upsampling, the reference's
+                                ablation path (cfg.model.use_resize_conv = false, score_unet.py:470-475, :589) */
 } sbgm_model_config;
 
 int sbgm_model_create(const sbgm_model_config* cfg, sbgm_model** out);
@@ -178,6 +180,12 @@ int64_t sbgm_conv_wino_packed_numel(int Cout, int c_pad);
 int sbgm_conv_wino_pack_weight(const float* w_oihw, float* packed, int Cout, int Cin, int c_pad, void* stream);
 
 /* nn.Upsample(scale_factor=2, mode="bilinear", align_corners=False).  score_unet.py:467 */
+/* ConvTranspose2d(k=2,s=2) = one 1x1 convolution to 4C channels (weights from sbgm_tconv_weight_to_oihw, bias repeated
+ * 4x) followed by depth->space; its backward is space->depth followed by the 1x1 convolution's backward. */
+int sbgm_depth_to_space2(const float* x /* [B,H,W,4C] */, float* y /* [B,2H,2W,C] */, int B, int H, int W, int C, void* stream);
+int sbgm_space_to_depth2(const float* y /* [B,2H,2W,C] */, float* x /* [B,H,W,4C] */, int B, int H, int W, int C, void* stream);
+int sbgm_tconv_weight_to_oihw(const float* w /* [Cin,Cout,2,2] */, float* oihw /* [4*Cout,Cin,1,1] */, int Cin, int Cout,
+                              void* stream);
 int sbgm_upsample2x_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream);
 /* nn.GroupNorm / nn.InstanceNorm2d (+ skip add, + time bias, + activation).  score_unet.py:480-483, :585-615.
  * gamma/beta NULL = no affine (InstanceNorm2d default).  stats_ws: >= 1024*B*G bytes. */

@@ -39,11 +39,11 @@ torch.set_num_threads(8)
 CPU = torch.device("cpu")
 
 
-def build_ref(n_cond, num_classes, heads=4, temb=256, layers=(2, 2, 2, 2)):
+def build_ref(n_cond, num_classes, heads=4, temb=256, layers=(2, 2, 2, 2), resize=True):
     enc = R.Encoder(input_channels=n_cond, time_embedding=temb, block_layers=list(layers),
                     num_classes=num_classes, n_heads=heads)
     dec = R.Decoder(last_fmap_channels=512, output_channels=1, time_embedding=temb, n_heads=heads,
-                    use_resize_conv=True, norm="group", gn_groups=8, activation=nn.SiLU)
+                    use_resize_conv=resize, norm="group", gn_groups=8, activation=nn.SiLU)
     return R.ScoreNet(R.marginal_prob_std_fn, enc, dec, device=CPU, debug_pre_sigma_div=False)
 
 
@@ -51,7 +51,7 @@ def pair(n_cond, num_classes, **kw):
     ref = build_ref(n_cond, num_classes, **kw)
     ora = O.build_scorenet(n_cond, num_classes=num_classes,
                            time_embedding=kw.get("temb", 256), n_heads=kw.get("heads", 4),
-                           block_layers=kw.get("layers", (2, 2, 2, 2)))
+                           block_layers=kw.get("layers", (2, 2, 2, 2)), use_resize_conv=kw.get("resize", True))
     rk = {k: tuple(v.shape) for k, v in ref.state_dict().items()}
     ok = {k: tuple(v.shape) for k, v in ora.state_dict().items()}
     assert rk == ok, set(rk.items()) ^ set(ok.items())
@@ -227,6 +227,44 @@ torch.manual_seed(10)
 noise = [torch.randn(2, 1, 32, 32) for _ in range(4)]
 np.savez_compressed(os.path.join(GOLD, "em_cfg_b2_32_3steps.npz"),
                     **npz({**{k: inp[k] for k in ("y", "cond_img", "lsm_cond", "topo_cond")}, "noise": torch.stack(noise), "mean_x": xr}))
+
+# ---- ConvTranspose2d decoder (model.use_resize_conv = false, score_unet.py:470-475): forward, loss and two gradients -------
+ref, ora, sd = pair(1, None, resize=False)
+tinp = inputs(4242, 2, 64, 1, False, 0)
+tout = {}
+for m in (ref, ora):
+    m.load_state_dict(sd)
+    m.eval()
+with torch.no_grad():
+    yr = ref(tinp["x"], tinp["t"], None, tinp["cond_img"])
+    yo = ora(tinp["x"], tinp["t"], None, tinp["cond_img"])
+report["transpose_decoder/eval"] = maxrel(yo, yr)
+assert report["transpose_decoder/eval"] <= 1e-6
+TPROBE = ["decoder.residual_layers.0.transpose.weight", "decoder.final_layer.transpose.bias", "encoder.conv2.weight"]
+tres = {}
+for m, mod in ((ref, R), (ora, O)):
+    m.load_state_dict(sd)
+    m.train()
+    m.zero_grad()
+    torch.manual_seed(41)
+    L = mod.loss_fn(m, tinp["x"], mod.marginal_prob_std_fn, cond_img=tinp["cond_img"])
+    L.backward()
+    pp = dict(m.named_parameters())
+    tres[mod.__name__] = (L.detach(), {k: pp[k].grad.clone() for k in TPROBE})
+report["transpose_decoder/loss"] = abs(float(tres[R.__name__][0] - tres[O.__name__][0]) / float(tres[R.__name__][0]))
+assert report["transpose_decoder/loss"] <= 1e-6
+for k in TPROBE:
+    report[f"transpose_decoder/grad/{k}"] = maxrel(tres[O.__name__][1][k], tres[R.__name__][1][k])
+    assert report[f"transpose_decoder/grad/{k}"] <= 1e-5
+torch.manual_seed(41)
+tt = torch.rand(2) * (1.0 - 1e-3) + 1e-3
+tz = torch.randn_like(tinp["x"])
+np.savez_compressed(os.path.join(GOLD, "transpose_decoder_b2_64.npz"),
+                    **npz({"x": tinp["x"], "t": tinp["t"], "cond_img": tinp["cond_img"], "score_eval": yr, "loss": tres[R.__name__][0],
+                           "t_used": tt, "z_used": tz,
+                           **{f"grad_sub::{k}": tres[R.__name__][1][k].reshape(-1)[:: (257 if tres[R.__name__][1][k].numel() > 4096 else 1)][:4096].clone()
+                              for k in TPROBE}}))
+state_manifest["ncond1_cls0_transpose"] = {k: [list(v.shape), hashlib.sha256(v.numpy().tobytes()).hexdigest()[:16]] for k, v in sd.items()}
 
 # ---- transforms / back-transforms: reference sbgm/special_transforms.py, imported as is --------------
 import sbgm.special_transforms as RT                                     # noqa: E402

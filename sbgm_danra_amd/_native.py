@@ -24,7 +24,7 @@ _vp, _i, _f, _i64, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_uint64
 class ModelConfig(C.Structure):
     _fields_ = [("n_lsm_channels", _i), ("n_topo_channels", _i), ("n_cond_channels", _i), ("time_embedding", _i),
                 ("block_layers", _i * 4), ("n_heads", _i), ("num_classes", _i), ("last_fmap_channels", _i),
-                ("decoder_norm", _i), ("gn_groups", _i), ("decoder_activation", _i), ("sigma", _f)]
+                ("decoder_norm", _i), ("gn_groups", _i), ("decoder_activation", _i), ("sigma", _f), ("decoder_transpose", _i)]
 
 
 class SamplerArgs(C.Structure):
@@ -70,6 +70,9 @@ SIGNATURES = {
     "sbgm_pointwise_chain": (_i, [_vp, _vp, _i64, _i, C.POINTER(C.c_int), C.POINTER(C.c_float), _vp]),
     "sbgm_sample_extremes": (_i, [_vp, _i, _i64, _f, _vp, _vp, _vp]),
     "sbgm_assemble_conditions": (_i, [C.POINTER(AssembleArgs), _vp]),
+    "sbgm_depth_to_space2": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "sbgm_space_to_depth2": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "sbgm_tconv_weight_to_oihw": (_i, [_vp, _vp, _i, _i, _vp]),
     "sbgm_extract_tiles": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "sbgm_stitch_tiles": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "sbgm_model_autotune": (_i, [_vp, _i, _i, _i, _vp]),

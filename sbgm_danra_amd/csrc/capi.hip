@@ -125,6 +125,16 @@ int sbgm_stitch_tiles(const float* tiles, const int* origins, float* domain, int
     return sbgm_launch_stitch_tiles(tiles, origins, domain, T, C, Hd, Wd, th, tw, ramp_len, ST);
 }
 
+int sbgm_depth_to_space2(const float* x, float* y, int B, int H, int W, int C, void* stream) {
+    return sbgm_launch_depth_space2(x, y, B, H, W, C, 1, ST);
+}
+int sbgm_space_to_depth2(const float* y, float* x, int B, int H, int W, int C, void* stream) {
+    return sbgm_launch_depth_space2(y, x, B, H, W, C, 0, ST);
+}
+int sbgm_tconv_weight_to_oihw(const float* w, float* oihw, int Cin, int Cout, void* stream) {
+    return sbgm_launch_tconv_weight(w, oihw, Cin, Cout, ST);
+}
+
 // ---- training path: backward entry points ---------------------------------------------------------------------------
 int sbgm_conv_pack_weight_dgrad(const float* w_oihw, float* packed, int Cout, int Cin, int KH, int KW, void* stream) {
     // operator of the data gradient: Cout' = Cin, Cin' = Cout (padded to 16), taps flipped

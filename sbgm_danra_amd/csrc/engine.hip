@@ -26,7 +26,7 @@ inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 inline int pad_channels(int c) { return c <= 4 ? 4 : c <= 8 ? 8 : (int)align_up(c, 16); }
 
 // ---- parameters ------------------------------------------------------------------------------------------------
-enum ParamKind { P_VEC, P_CONV, P_COUT1, P_IGNORE };
+enum ParamKind { P_VEC, P_CONV, P_COUT1, P_IGNORE, P_TCONV, P_VEC4 };   // TCONV: ConvTranspose2d(2,2) weight; VEC4: vector stored 4x
 struct Param {
     std::string name;
     ParamKind kind = P_VEC;
@@ -218,8 +218,14 @@ int sbgm_model::build(const sbgm_model_config& c) {
     int dc = c.last_fmap_channels;
     auto dec_block = [&](const std::string& pre, DecW& d, int ci, int co, bool with_norm, bool with_attn) {
         d.cin = ci; d.cout = co; d.has_attn = with_attn;
-        d.up.w = convw(pre + ".conv_up.weight", ci, ci, 3, 3, 0, true);
-        d.up.b = vec(pre + ".conv_up.bias", ci);
+        if (c.decoder_transpose) {       // ablation path: ConvTranspose2d(ci, ci, 2, 2) as a 1x1 conv to 4*ci phase-major channels
+            d.up.w = add(pre + ".transpose.weight", P_TCONV, (int64_t)ci * ci * 4);
+            d.up.w->cout = 4 * ci; d.up.w->cin = ci; d.up.w->kh = d.up.w->kw = 1; d.up.w->cs = (int)align_up(ci, 16);
+            d.up.b = add(pre + ".transpose.bias", P_VEC4, ci);
+        } else {
+            d.up.w = convw(pre + ".conv_up.weight", ci, ci, 3, 3, 0, true);
+            d.up.b = vec(pre + ".conv_up.bias", ci);
+        }
         const bool affine = with_norm && c.decoder_norm == SBGM_NORM_GROUP;
         d.n1g = affine ? vec(pre + ".norm1.weight", ci) : nullptr;
         d.n1b = affine ? vec(pre + ".norm1.bias", ci) : nullptr;
@@ -256,7 +262,8 @@ int sbgm_model::build(const sbgm_model_config& c) {
     size_t total = 0;
     for (auto& up : params) {
         Param* p = up.get();
-        if (p->kind == P_CONV) p->dev_floats = (size_t)sbgm_conv_nsteps(p->kh, p->kw, p->cs) * p->cout * 16;
+        if (p->kind == P_CONV || p->kind == P_TCONV) p->dev_floats = (size_t)sbgm_conv_nsteps(p->kh, p->kw, p->cs) * p->cout * 16;
+        else if (p->kind == P_VEC4) p->dev_floats = (size_t)p->numel * 4;
         else if (p->kind == P_IGNORE) p->dev_floats = 0;
         else p->dev_floats = (size_t)p->numel;
         if (p->wino) p->wino_floats = sbgm_wino_packed_floats(p->cout, p->cs);
@@ -602,12 +609,20 @@ int sbgm_model::forward(const float* x, const float* t, const int64_t* y, const 
         SBGM_CHECK(oh == fh[3 - i] && ow == fw[3 - i] && d.cout == FMAP_CH[3 - i], "decoder/skip shape mismatch at block %d", i);
         float* up = wsalloc((size_t)B * oh * ow * d.cin);
         if (!up) return 1;
-        if (sbgm_launch_upsample2x(cur, up, B, ch, cw_, d.cin, st)) return 1;
         float* a = wsalloc((size_t)B * oh * ow * d.cin);
         if (!a) return 1;
         ConvParams p{};
-        p.x = up; p.wp = d.up.w->dev; p.wp_wino = d.up.w->dev_wino; p.out = a; p.bias = d.up.b->dev; p.B = B; p.H = oh; p.W = ow; p.Cs = d.cin; p.Cout = d.cin;
-        if (conv(ConvGeom{3, 3, 1, 1}, p, st)) return 1;
+        if (cfg.decoder_transpose) {                 // ConvTranspose2d: 1x1 conv to 4*cin phase-major channels, then depth -> space
+            p.x = cur; p.wp = d.up.w->dev; p.out = up; p.bias = d.up.b->dev; p.B = B; p.H = ch; p.W = cw_; p.Cs = d.cin; p.Cout = 4 * d.cin;
+            if (conv(ConvGeom{1, 1, 1, 0}, p, st)) return 1;
+            if (sbgm_launch_depth_space2(up, a, B, ch, cw_, d.cin, 1, st)) return 1;
+            p = ConvParams{};
+            p.B = B; p.H = oh; p.W = ow; p.Cs = d.cin;
+        } else {
+            if (sbgm_launch_upsample2x(cur, up, B, ch, cw_, d.cin, st)) return 1;
+            p.x = up; p.wp = d.up.w->dev; p.wp_wino = d.up.w->dev_wino; p.out = a; p.bias = d.up.b->dev; p.B = B; p.H = oh; p.W = ow; p.Cs = d.cin; p.Cout = d.cin;
+            if (conv(ConvGeom{3, 3, 1, 1}, p, st)) return 1;
+        }
         if (sbgm_launch_groupnorm(a, a, d.n1g ? d.n1g->dev : nullptr, d.n1b ? d.n1b->dev : nullptr, nullptr, nullptr,
                                   SBGM_ACT_NONE, B, oh * ow, d.cin, groups(d.cin), GN_EPS, stats, st)) return 1;
         float* c2 = wsalloc((size_t)B * oh * ow * d.cout);
@@ -623,8 +638,16 @@ int sbgm_model::forward(const float* x, const float* t, const int64_t* y, const 
         const int ci = dec[3].cout;
         float* up = wsalloc((size_t)B * H * W * ci);
         if (!up) return 1;
-        if (sbgm_launch_upsample2x(cur, up, B, ch, cw_, ci, st)) return 1;
         ConvParams p{};
+        if (cfg.decoder_transpose) {
+            float* a = wsalloc((size_t)B * H * W * ci);
+            if (!a) return 1;
+            p.x = cur; p.wp = fin_up.w->dev; p.out = up; p.bias = fin_up.b->dev; p.B = B; p.H = ch; p.W = cw_; p.Cs = ci; p.Cout = 4 * ci;
+            if (conv(ConvGeom{1, 1, 1, 0}, p, st)) return 1;
+            if (sbgm_launch_depth_space2(up, a, B, ch, cw_, ci, 1, st)) return 1;
+            return sbgm_launch_conv3x3_cout1(a, fin_conv.w->dev, fin_conv.b->dev, t, cfg.sigma, out, B, H, W, ci, st);
+        }
+        if (sbgm_launch_upsample2x(cur, up, B, ch, cw_, ci, st)) return 1;
         p.x = up; p.wp = fin_up.w->dev; p.wp_wino = fin_up.w->dev_wino; p.bias = fin_up.b->dev; p.B = B; p.H = H; p.W = W; p.Cs = ci; p.Cout = ci;
         if (ci == 64) {
             // conv_up's 64-channel output feeds only the linear 3x3 Cout=1 conv: project onto its 9 taps in the epilogue
@@ -863,6 +886,17 @@ int sbgm_model_set_param(sbgm_model* m, const char* name, const void* data, int6
     } else if (p->kind == P_CONV) {
         if (sbgm_launch_pack_conv_weight(src, p->dev, p->cout, p->cin, p->kh, p->kw, p->cs, st)) return 1;
         if (p->wino && sbgm_launch_pack_wino_weight(src, p->dev_wino, p->cout, p->cin, p->cs, st)) return 1;
+    } else if (p->kind == P_TCONV) {             // [Cin][Cout][2][2] -> OIHW [4*Cout][Cin][1][1] (scratch) -> packed
+        float* tmp = nullptr;
+        SBGM_HIP(hipMalloc(&tmp, (size_t)numel * 4));
+        int rc = sbgm_launch_tconv_weight(src, tmp, p->cin, p->cout / 4, st);
+        if (!rc) rc = sbgm_launch_pack_conv_weight(tmp, p->dev, p->cout, p->cin, 1, 1, p->cs, st);
+        (void)hipStreamSynchronize(st);
+        (void)hipFree(tmp);
+        if (rc) return rc;
+    } else if (p->kind == P_VEC4) {
+        for (int r = 0; r < 4; ++r)
+            SBGM_HIP(hipMemcpyAsync(p->dev + (size_t)r * numel, src, (size_t)numel * 4, hipMemcpyDeviceToDevice, st));
     } else {
         if (sbgm_launch_pack_cout1_weight(src, p->dev, p->cin, st)) return 1;
     }

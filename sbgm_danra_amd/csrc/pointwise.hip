@@ -323,6 +323,53 @@ int sbgm_launch_upsample2x(const float* x, float* y, int B, int H, int W, int C,
     return 0;
 }
 
+// ---- ConvTranspose2d(k=2, s=2) support (decoder ablation path, reference score_unet.py:470-475, :589) -----------------------
+// The transposed convolution is 4 independent 1x1 convolutions (one per output phase (dy,dx)); the engine runs them as ONE
+// 1x1 implicit GEMM with 4C output channels ordered (dy, dx, co) and these two permutations move between that
+// "depth" layout [B][H][W][4C] and the upsampled "space" layout [B][2H][2W][C].
+namespace {
+__global__ __launch_bounds__(256) void depth_space2_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H,
+                                                           int W, int C, int to_space, size_t total4) {
+    const int c4n = C >> 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        // i enumerates float4 slots of the SPACE tensor [B][2H][2W][C/4]
+        const int c4 = (int)(i % c4n);
+        size_t r = i / c4n;
+        const int X = (int)(r % (2 * W)); r /= 2 * W;
+        const int Y = (int)(r % (2 * H));
+        const int b = (int)(r / (2 * H));
+        const size_t d = ((((size_t)b * H + (Y >> 1)) * W + (X >> 1)) * 4 + ((Y & 1) * 2 + (X & 1))) * c4n + c4;
+        if (to_space) reinterpret_cast<f32x4*>(out)[i] = reinterpret_cast<const f32x4*>(in)[d];
+        else reinterpret_cast<f32x4*>(out)[d] = reinterpret_cast<const f32x4*>(in)[i];
+    }
+}
+
+// ConvTranspose2d weight [Cin][Cout][2][2] -> 1x1 conv weight OIHW [(dy*2+dx)*Cout + co][ci]
+__global__ void tconv_weight_kernel(const float* __restrict__ w, float* __restrict__ o, int Cin, int Cout) {
+    const int n = Cin * Cout * 4;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+        const int ci = i % Cin;
+        const int row = i / Cin;                 // (dy*2+dx)*Cout + co
+        const int co = row % Cout, ph = row / Cout;
+        o[i] = w[((size_t)ci * Cout + co) * 4 + ph];
+    }
+}
+}  // namespace
+
+int sbgm_launch_depth_space2(const float* in, float* out, int B, int H, int W, int C, int to_space, hipStream_t st) {
+    SBGM_CHECK(C % 4 == 0, "depth<->space: C=%d must be a multiple of 4", C);
+    const size_t total4 = (size_t)B * 4 * H * W * (C / 4);
+    hipLaunchKernelGGL(depth_space2_kernel, dim3(stream_blocks(total4 * 4)), dim3(256), 0, st, in, out, B, H, W, C, to_space, total4);
+    SBGM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sbgm_launch_tconv_weight(const float* w, float* oihw, int Cin, int Cout, hipStream_t st) {
+    hipLaunchKernelGGL(tconv_weight_kernel, dim3(std::min((Cin * Cout * 4 + 255) / 256, 4096)), dim3(256), 0, st, w, oihw, Cin, Cout);
+    SBGM_LAUNCH_CHECK();
+    return 0;
+}
+
 int sbgm_launch_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps,
                         float* scale, float* bias, int C, hipStream_t st) {
     hipLaunchKernelGGL(bn_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, st, gamma, beta, mean, var, eps, scale, bias, C);

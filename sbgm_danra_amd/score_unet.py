@@ -152,8 +152,8 @@ class DecoderBlock(_NativeOnly):
             self.upsample = nn.Upsample(scale_factor=upsample_scale, mode="bilinear", align_corners=False)
             self.conv_up = nn.Conv2d(input_channels, input_channels, kernel_size=3, padding=1, bias=True)
         else:
-            # ablation path of the reference (score_unet.py:470-475); parameters are kept so checkpoints load,
-            # but the native engine only implements the default resize-conv path.
+            # ablation path of the reference (score_unet.py:470-475): ConvTranspose2d(k=2, s=2), run natively as one 1x1
+            # implicit GEMM to 4C phase-major channels + a depth->space permutation
             self.transpose = nn.ConvTranspose2d(input_channels, input_channels, kernel_size=upsample_scale,
                                                 stride=upsample_scale)
 
@@ -210,8 +210,6 @@ class _Engine:
 
     def __init__(self, net: "ScoreNet", n_lsm: int, n_topo: int, n_cond: int):
         enc, dec = net.encoder, net.decoder
-        if not dec.use_resize_conv:
-            raise NotImplementedError("model.use_resize_conv=false (ConvTranspose2d decoder) is not implemented natively")
         if 1 + n_lsm + n_topo + n_cond != enc.input_channels:
             raise ValueError(f"input channel mismatch: x(1)+lsm({n_lsm})+topo({n_topo})+cond_img({n_cond}) != "
                              f"encoder.conv1 in_channels ({enc.input_channels})")
@@ -221,7 +219,7 @@ class _Engine:
         cfg = N.ModelConfig(n_lsm, n_topo, n_cond, enc.time_embedding, (C.c_int * 4)(*enc.block_layers), enc.n_heads,
                             enc.num_classes or 0, dec.last_fmap_channels,
                             N.NORM_GROUP if dec.norm == "group" else N.NORM_INSTANCE, dec.gn_groups, act,
-                            float(getattr(net, "sigma", 25.0)))
+                            float(getattr(net, "sigma", 25.0)), 0 if dec.use_resize_conv else 1)
         self.lib = N.lib()
         h = C.c_void_p()
         N.check(self.lib.sbgm_model_create(C.byref(cfg), C.byref(h)))

@@ -219,6 +219,34 @@ class UpsampleFn(torch.autograd.Function):
         return dx
 
 
+class DepthToSpaceFn(torch.autograd.Function):
+    """[B,H,W,4C] (phase-major channels) -> [B,2H,2W,C]; backward is the inverse permutation"""
+    @staticmethod
+    def forward(ctx, x):
+        B, H, W, C4 = x.shape
+        y = torch.empty(B, 2 * H, 2 * W, C4 // 4, device=x.device)
+        N.check(_L().sbgm_depth_to_space2(x.data_ptr(), y.data_ptr(), B, H, W, C4 // 4, _st()))
+        ctx.dims = (B, H, W, C4)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, H, W, C4 = ctx.dims
+        dy = dy.contiguous()
+        dx = torch.empty(B, H, W, C4, device=dy.device)
+        N.check(_L().sbgm_space_to_depth2(dy.data_ptr(), dx.data_ptr(), B, H, W, C4 // 4, _st()))
+        return dx
+
+
+def conv_transpose2x(x, mod):
+    """nn.ConvTranspose2d(C, C, 2, stride=2) (reference score_unet.py:472-475, :589) = 1x1 conv to 4C phase-major channels
+    + depth->space.  The weight/bias rearrangement is plain autograd-tracked tensor indexing on the parameters."""
+    ci, co = mod.weight.shape[0], mod.weight.shape[1]
+    w1 = mod.weight.permute(2, 3, 1, 0).reshape(4 * co, ci, 1, 1).contiguous()       # [(dy,dx,co), ci]
+    b4 = None if mod.bias is None else mod.bias.repeat(4)
+    return DepthToSpaceFn.apply(ConvFn.apply(x, w1, b4, None, None, 1, 0))
+
+
 class ActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, act):
@@ -328,9 +356,12 @@ def _attention(mod, x):                               # x: [B, H, W, C] -> same 
 
 def forward_train(net, x, t, y, cond, lsm, topo):
     enc, dec = net.encoder, net.decoder
-    if not dec.use_resize_conv:
-        raise NotImplementedError("model.use_resize_conv=false is not implemented natively")
     sigma = float(net.sigma)
+
+    def upsampled(blk, h):        # (A) of DecoderBlock: resize-conv (default) or the ConvTranspose2d ablation path
+        if dec.use_resize_conv:
+            return ConvFn.apply(UpsampleFn.apply(h), blk.conv_up.weight, blk.conv_up.bias, None, None, 1, 1)
+        return conv_transpose2x(h, blk.transpose)
     tlabel = enc.label_emb.weight if (y is not None and enc.num_classes is not None) else None
     if y is not None and tlabel is None:
         raise ValueError("y given but the model has no label embedding")
@@ -363,7 +394,7 @@ def forward_train(net, x, t, y, cond, lsm, topo):
         G1 = max(1, min(dec.gn_groups, blk.input_channels)) if group else blk.input_channels
         G2 = max(1, min(dec.gn_groups, blk.output_channels)) if group else blk.output_channels
         g = lambda n: (n.weight, n.bias) if group else (None, None)   # noqa: E731
-        a = ConvFn.apply(UpsampleFn.apply(cur), blk.conv_up.weight, blk.conv_up.bias, None, None, 1, 1)
+        a = upsampled(blk, cur)
         a = GroupNormFn.apply(a, *g(blk.norm1), None, None, N.NONE, G1, 1e-5)
         c2 = ConvFn.apply(a, blk.conv.weight, blk.conv.bias, None, None, 1, 1)
         tbd = tproj(blk.sinusoidal_embedding, blk.time_projection_layer, False)
@@ -371,5 +402,5 @@ def forward_train(net, x, t, y, cond, lsm, topo):
         if blk.compute_attn:
             cur = _attention(blk.attention, cur)
     fin = dec.final_layer
-    a = ConvFn.apply(UpsampleFn.apply(cur), fin.conv_up.weight, fin.conv_up.bias, None, None, 1, 1)
+    a = upsampled(fin, cur)
     return Cout1Fn.apply(a, fin.conv.weight, fin.conv.bias, t, sigma)

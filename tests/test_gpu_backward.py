@@ -189,6 +189,32 @@ def test_loss_gradients_match_reference_goldens(golden_dir):
         assert maxrel(gr[:: max(1, gr.numel() // 2048)][:2048], g[k]) < 2e-4, k
 
 
+def test_transpose_decoder_matches_reference_goldens(golden_dir):
+    """the ConvTranspose2d ablation decoder (model.use_resize_conv = false): forward, loss and gradients vs the reference"""
+    import sbgm_danra_amd as S
+    g = load_golden(os.path.join(golden_dir, "transpose_decoder_b2_64.npz"))
+    ora, net, _ = build_pair(1, resize=False)
+    assert "decoder.residual_layers.0.transpose.weight" in net.state_dict() and "decoder.final_layer.conv_up.weight" not in net.state_dict()
+    net.eval()
+    x, cond, t = g["x"].cuda(), g["cond_img"].cuda(), g["t"].cuda()
+    with torch.no_grad():
+        assert maxrel(net(x, t, cond_img=cond).cpu(), g["score_eval"]) <= 1e-4
+        got = S.pc_sampler(net, S.marginal_prob_std_fn, S.diffusion_coeff_fn, batch_size=2, num_steps=2, device="cuda", img_size=64,
+                           cond_img=cond, seed=3)
+    assert torch.isfinite(got).all()
+    net.train()
+    tu, zu = g["t_used"].cuda(), g["z_used"].cuda()
+    std = S.marginal_prob_std_fn(tu)
+    score = net(x + std[:, None, None, None] * zu, tu, cond_img=cond)
+    loss = torch.mean(torch.sum((score * std[:, None, None, None] + zu) ** 2, dim=(1, 2, 3)))
+    loss.backward()
+    assert abs(float(loss) / float(g["loss"]) - 1) < 1e-5
+    params = dict(net.named_parameters())
+    for k in [k for k in g if k.startswith("grad_sub::")]:
+        gr = params[k[10:]].grad.reshape(-1).cpu()
+        assert maxrel(gr[:: (257 if gr.numel() > 4096 else 1)][:4096], g[k]) < 5e-4, k
+
+
 def _batch(gen, B=3, hw=64):
     x, cond = torch.randn(B, 1, hw, hw, generator=gen), torch.randn(B, 1, hw, hw, generator=gen)
     lsm = torch.cat([(torch.rand(B, 1, hw, hw, generator=gen) > 0.5).float(), torch.ones(B, 1, hw, hw)], 1)
