@@ -36,13 +36,14 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(const ConvParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, kq = lane >> 4;
 
-    // block -> (co tile, image, tile row, tile col); XCD-contiguous so neighbouring tiles share halos in one L2
+    // block -> (image, tile row, tile col, co tile), co tile fastest: the output-channel slices of one pixel tile run back to
+    // back on one XCD (XCD-contiguous ids), so the halo patch is fetched into that L2 once and neighbouring tiles share halos
     int t = xcd_contiguous_block(blockIdx.x, gridDim.x);
-    const int tiles_x = p.W / TW, tiles_y = (p.H + TH - 1) / TH;
+    const int tiles_x = p.W / TW, tiles_y = (p.H + TH - 1) / TH, n_co = p.Cout / NCO;
+    const int co_tile = t % n_co; t /= n_co;
     const int tx = t % tiles_x; t /= tiles_x;
-    const int ty = t % tiles_y; t /= tiles_y;
-    const int b = t % p.B;
-    const int co_tile = t / p.B;
+    const int ty = t % tiles_y;
+    const int b = t / tiles_y;
     const int co0 = co_tile * NCO, x0 = tx * TW, y0 = ty * TH;
 
     const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
