@@ -99,20 +99,51 @@ def train_bench(a):
     net = build_model(dev, n_cond=4)
     net.train()
     parallel.broadcast_parameters(net)
-    opt = torch.optim.Adam(net.parameters(), lr=5e-4, weight_decay=1e-6)
+    # fused multi-tensor Adam: the reference's default foreach Adam issues ~330 tiny per-parameter kernels per step
+    opt = torch.optim.Adam(net.parameters(), lr=5e-4, weight_decay=1e-6, fused=True)
     bucket = parallel.GradientBucket(net.parameters()) if world > 1 else None
     B, HW = (a.batch if a.batch != 32 else 8), a.size
     g = torch.Generator().manual_seed(42 + rank)
     x, cond = torch.randn(B, 1, HW, HW, generator=g).to(dev), torch.randn(B, 4, HW, HW, generator=g).to(dev)
 
-    def step():
-        opt.zero_grad()
+    graphed = not a.no_graph
+    def fwd_bwd():
         loss = S.loss_fn(net, x, S.marginal_prob_std_fn, cond_img=cond)
         loss.backward()
+        return loss
+
+    def finish():
         if bucket is not None:
             bucket.all_reduce_()
         opt.step()
-        return loss
+
+    if graphed:
+        # The step's launch sequence is static (shapes, tiles and the RNG draw sites are fixed), so forward + backward are
+        # captured once into a hipGraph (torch.cuda.graphs) and replayed: one host call per step instead of ~900 launches
+        # through Python.  The gradient all-reduce and the optimizer run eagerly after the replay.
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(3):
+                opt.zero_grad(set_to_none=True)
+                fwd_bwd()
+                finish()
+        torch.cuda.current_stream().wait_stream(side)
+        graph = torch.cuda.CUDAGraph()
+        opt.zero_grad(set_to_none=True)
+        with torch.cuda.graph(graph):
+            static_loss = fwd_bwd()
+
+        def step():
+            graph.replay()
+            finish()
+            return static_loss
+    else:
+        def step():
+            opt.zero_grad()
+            loss = fwd_bwd()
+            finish()
+            return loss
 
     for _ in range(max(1, a.warmup)):
         step()
@@ -135,7 +166,8 @@ def train_bench(a):
                           "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": f"{HW}x{HW} 4-cond->1-target (C_in=5), batch {B}/GPU, loss_fn + backward + Adam"
-                                                 + (", RCCL gradient all-reduce (76 MB bucket)" if world > 1 else ""),
+                                                 + (", RCCL gradient all-reduce (76 MB bucket)" if world > 1 else "")
+                                                 + (", forward+backward replayed as one hipGraph" if graphed else ""),
                                      "global_batch": B * world, "final_loss": float(loss.detach())}}), flush=True)
     if world > 1:
         dist.destroy_process_group()

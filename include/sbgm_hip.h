@@ -175,17 +175,22 @@ typedef struct sbgm_conv_args {
     int64_t ws_floats;
 } sbgm_conv_args;
 int sbgm_conv2d_fwd(const sbgm_conv_args* a, void* stream);
+/* Times the kernel / tile / split candidates for exactly this call (same operands; launches are idempotent; synchronises)
+ * and writes the fastest as tile[6] = {tile_co, tile_px, splits, waves_per_tile, winograd bit 0, winograd bit 1}, the values
+ * to put into sbgm_conv_args.  Winograd candidates are skipped (they need the transformed weights); split-K candidates are
+ * considered when a->ws is given.  Used by the training path, whose convolutions run op by op. */
+int sbgm_conv2d_tune(const sbgm_conv_args* a, int* tile, void* stream);
 /* Winograd F(2,3)-along-rows weight transform for 3x3 kernels: OIHW -> U[kh][c/16][xi][Cout][16] */
 int64_t sbgm_conv_wino_packed_numel(int Cout, int c_pad);
 int sbgm_conv_wino_pack_weight(const float* w_oihw, float* packed, int Cout, int Cin, int c_pad, void* stream);
 
-/* nn.Upsample(scale_factor=2, mode="bilinear", align_corners=False).  score_unet.py:467 */
 /* ConvTranspose2d(k=2,s=2) = one 1x1 convolution to 4C channels (weights from sbgm_tconv_weight_to_oihw, bias repeated
  * 4x) followed by depth->space; its backward is space->depth followed by the 1x1 convolution's backward. */
 int sbgm_depth_to_space2(const float* x /* [B,H,W,4C] */, float* y /* [B,2H,2W,C] */, int B, int H, int W, int C, void* stream);
 int sbgm_space_to_depth2(const float* y /* [B,2H,2W,C] */, float* x /* [B,H,W,4C] */, int B, int H, int W, int C, void* stream);
 int sbgm_tconv_weight_to_oihw(const float* w /* [Cin,Cout,2,2] */, float* oihw /* [4*Cout,Cin,1,1] */, int Cin, int Cout,
                               void* stream);
+/* nn.Upsample(scale_factor=2, mode="bilinear", align_corners=False).  score_unet.py:467 */
 int sbgm_upsample2x_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream);
 /* nn.GroupNorm / nn.InstanceNorm2d (+ skip add, + time bias, + activation).  score_unet.py:480-483, :585-615.
  * gamma/beta NULL = no affine (InstanceNorm2d default).  stats_ws: >= 1024*B*G bytes. */

@@ -63,6 +63,20 @@ int sbgm_conv2d_fwd(const sbgm_conv_args* a, void* stream) {
     return sbgm_launch_conv(ConvGeom{a->KH, a->KW, a->stride, a->pad}, p, t, a->ws, ST);
 }
 
+int sbgm_conv2d_tune(const sbgm_conv_args* a, int* tile, void* stream) {
+    SBGM_CHECK(a && tile && a->x && a->w_packed && a->out, "conv2d_tune: null argument");
+    SBGM_CHECK(a->Cout % 32 == 0, "conv2d_tune: Cout=%d must be a multiple of 32", a->Cout);
+    ConvParams p{};
+    p.x = a->x; p.wp = a->w_packed; p.out = a->out; p.scale = a->scale; p.bias = a->bias; p.tbias = a->tbias;
+    p.res = a->residual; p.B = a->B; p.H = a->H; p.W = a->W; p.Cs = a->c_pad; p.Cout = a->Cout;
+    p.act = a->act; p.tbias_after_act = a->tbias_after_act;
+    p.in_dil = a->in_dil; p.out_h = a->out_h; p.out_w = a->out_w;
+    ConvTile best{a->Cout % 64 == 0 ? 4 : 2, 2, 1, 1, 0, 0};
+    if (sbgm_tune_conv(ConvGeom{a->KH, a->KW, a->stride, a->pad}, p, a->ws, a->ws ? (size_t)a->ws_floats : 0, ST, &best)) return 1;
+    tile[0] = best.fco; tile[1] = best.fpx; tile[2] = best.splits; tile[3] = best.ws; tile[4] = best.wino; tile[5] = best.lds;
+    return 0;
+}
+
 int sbgm_upsample2x_fwd(const float* x, float* y, int B, int H, int W, int C, void* stream) {
     return sbgm_launch_upsample2x(x, y, B, H, W, C, ST);
 }

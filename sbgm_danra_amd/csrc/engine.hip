@@ -361,6 +361,85 @@ ConvTile sbgm_model::pick_tile(const ConvGeom& g, const ConvParams& p) {
     return ConvTile{fco, fpx, splits, ws, 0, 0};
 }
 
+// Times the tile candidates (template x tile x waves-per-tile x split-K) of ONE convolution on its real operands and returns
+// the fastest in *best (in: the fallback).  A launch never reads what it writes, so repeating it is harmless.  Synchronises.
+int sbgm_tune_conv(const ConvGeom& g, const ConvParams& p, float* partial, size_t partial_floats, hipStream_t st, ConvTile* best) {
+    const int OH = p.out_h > 0 ? p.out_h : (p.H + 2 * g.pad - g.kh) / g.stride + 1;
+    const int OW = p.out_w > 0 ? p.out_w : (p.W + 2 * g.pad - g.kw) / g.stride + 1;
+    const size_t mc = (size_t)p.B * OH * OW * p.Cout;
+    const int nsteps = sbgm_conv_nsteps(g.kh, g.kw, p.Cs);
+    auto launch = [&](const ConvTile& ct) -> int {
+        ConvParams q = p;
+        if (!ct.wino && !ct.lds) return sbgm_launch_conv(g, q, ct, partial, st);
+        if (ct.wino) q.wp = q.wp_wino;
+        return ct.lds ? sbgm_launch_conv_lds(q, ct, st) : sbgm_launch_conv_wino(q, ct, st);
+    };
+    std::vector<ConvTile> cands;
+    const int tiles[6][2] = {{4, 4}, {4, 2}, {4, 1}, {2, 4}, {2, 2}, {2, 1}};
+    for (auto& t : tiles) {
+        if (p.Cout % (16 * t[0])) continue;
+        if (p.proj_w && 16 * t[0] != p.Cout) continue;
+        const long ntile = (long)(((size_t)p.B * OH * OW + 16 * t[1] - 1) / (16 * t[1])) * (p.Cout / (16 * t[0]));
+        for (int ws : {1, 2, 4}) {
+            if (ws > 1 && (nsteps / ws < 2 || ntile * ws > 32768)) continue;
+            for (int sp : {1, 2, 4, 8, 16}) {
+                if (sp > 1 && (p.proj_w || !partial || nsteps / (sp * ws) < 2 || ntile * ws >= 4096)) continue;   // already enough waves
+                cands.push_back(ConvTile{t[0], t[1], sp, ws, 0, 0});
+            }
+        }
+    }
+    const bool s1 = g.kh == 3 && g.kw == 3 && g.stride == 1 && g.pad == 1 && p.in_dil <= 1 &&
+                    (p.out_h == 0 || (p.out_h == p.H && p.out_w == p.W));
+    if (p.wp_wino != nullptr && s1 && p.W % 2 == 0) {
+        const int wt[4][2] = {{4, 1}, {2, 2}, {2, 1}, {4, 2}};
+        const int nsw = 3 * (p.Cs / 16);
+        for (auto& t : wt) {
+            if (p.Cout % (16 * t[0])) continue;
+            if (p.proj_w && 16 * t[0] != p.Cout) continue;
+            for (int ws : {1, 2, 4}) {
+                if (ws > 1 && nsw / ws < 2) continue;
+                cands.push_back(ConvTile{t[0], t[1], 1, ws, 1, 0});
+            }
+        }
+    }
+    if (s1 && p.W % 16 == 0 && p.Cs % 16 == 0 && getenv("SBGM_NO_LDS_CONV") == nullptr) {
+        const int dt[5][2] = {{4, 1}, {4, 2}, {4, 4}, {2, 2}, {2, 4}};
+        for (auto& t : dt) {
+            if (p.Cout % (16 * t[0]) || (p.proj_w && 16 * t[0] != p.Cout)) continue;
+            cands.push_back(ConvTile{t[0], t[1], 1, 1, 0, 1});
+        }
+        const int wt2[4][2] = {{4, 1}, {4, 2}, {2, 1}, {2, 2}};
+        if (p.wp_wino)
+            for (auto& t : wt2) {
+                if (p.Cout % (16 * t[0]) || (p.proj_w && 16 * t[0] != p.Cout)) continue;
+                cands.push_back(ConvTile{t[0], t[1], 1, 1, 1, 1});
+            }
+    }
+    hipEvent_t e0, e1;
+    SBGM_HIP(hipEventCreate(&e0));
+    SBGM_HIP(hipEventCreate(&e1));
+    float best_ms = 1e30f;
+    int rc = 0;
+    for (int round = 0; round < 2 && !rc; ++round)          // two interleaved rounds, keep each candidate's best (DVFS / noise)
+        for (auto& ct : cands) {
+            if (ct.splits > 1 && mc * ct.splits > partial_floats) continue;
+            constexpr int REPS = 6;
+            for (int rep = 0; rep <= REPS && !rc; ++rep) {
+                if (rep == 1) (void)hipEventRecord(e0, st);
+                rc = launch(ct);
+            }
+            if (rc) break;
+            (void)hipEventRecord(e1, st);
+            (void)hipEventSynchronize(e1);
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            if (ms < best_ms) { best_ms = ms; *best = ct; }
+        }
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return rc;
+}
+
 int sbgm_model::conv(const ConvGeom& g, ConvParams p, hipStream_t st) {
     const int OH = (p.H + 2 * g.pad - g.kh) / g.stride + 1, OW = (p.W + 2 * g.pad - g.kw) / g.stride + 1;
     const size_t mc = (size_t)p.B * OH * OW * p.Cout;
@@ -368,67 +447,8 @@ int sbgm_model::conv(const ConvGeom& g, ConvParams p, hipStream_t st) {
         // time every candidate on this op, keep the fastest
         ConvOpKey key{g.kh, g.kw, g.stride, g.pad, p.B, p.H, p.W, p.Cs, p.Cout, p.proj_w != nullptr};
         if (tuned.find(key) == tuned.end()) {
-            const int nsteps = sbgm_conv_nsteps(g.kh, g.kw, p.Cs);
-            std::vector<ConvTile> cands;
-            const int tiles[6][2] = {{4, 4}, {4, 2}, {4, 1}, {2, 4}, {2, 2}, {2, 1}};
-            for (auto& t : tiles) {
-                if (p.Cout % (16 * t[0])) continue;
-                if (p.proj_w && 16 * t[0] != p.Cout) continue;
-                const long ntile = (long)(((size_t)p.B * OH * OW + 16 * t[1] - 1) / (16 * t[1])) * (p.Cout / (16 * t[0]));
-                for (int ws : {1, 2, 4}) {
-                    if (ws > 1 && (nsteps / ws < 2 || ntile * ws > 32768)) continue;
-                    for (int sp : {1, 2, 4, 8, 16}) {
-                        if (sp > 1 && (p.proj_w || nsteps / (sp * ws) < 2 || ntile * ws >= 4096)) continue;   // already enough waves
-                        cands.push_back(ConvTile{t[0], t[1], sp, ws, 0, 0});
-                    }
-                }
-            }
-            if (p.wp_wino != nullptr && g.kh == 3 && g.kw == 3 && g.stride == 1 && g.pad == 1 && p.W % 2 == 0) {
-                const int wt[4][2] = {{4, 1}, {2, 2}, {2, 1}, {4, 2}};
-                const int nsw = 3 * (p.Cs / 16);
-                for (auto& t : wt) {
-                    if (p.Cout % (16 * t[0])) continue;
-                    if (p.proj_w && 16 * t[0] != p.Cout) continue;
-                    for (int ws : {1, 2, 4}) {
-                        if (ws > 1 && nsw / ws < 2) continue;
-                        cands.push_back(ConvTile{t[0], t[1], 1, ws, 1, 0});
-                    }
-                }
-            }
-            if (g.kh == 3 && g.kw == 3 && g.stride == 1 && g.pad == 1 && p.W % 16 == 0 && p.Cs % 16 == 0 && getenv("SBGM_NO_LDS_CONV") == nullptr) {
-                const int dt[5][2] = {{4, 1}, {4, 2}, {4, 4}, {2, 2}, {2, 4}};
-                for (auto& t : dt) {
-                    if (p.Cout % (16 * t[0]) || (p.proj_w && 16 * t[0] != p.Cout)) continue;
-                    cands.push_back(ConvTile{t[0], t[1], 1, 1, 0, 1});
-                }
-                const int wt2[4][2] = {{4, 1}, {4, 2}, {2, 1}, {2, 2}};
-                if (p.wp_wino)
-                    for (auto& t : wt2) {
-                        if (p.Cout % (16 * t[0]) || (p.proj_w && 16 * t[0] != p.Cout)) continue;
-                        cands.push_back(ConvTile{t[0], t[1], 1, 1, 1, 1});
-                    }
-            }
-            hipEvent_t e0, e1;
-            SBGM_HIP(hipEventCreate(&e0));
-            SBGM_HIP(hipEventCreate(&e1));
-            float best = 1e30f;
             ConvTile best_t = pick_tile(g, p);
-            for (int round = 0; round < 2; ++round)          // two interleaved rounds, keep each candidate's best (DVFS / noise)
-                for (auto& ct : cands) {
-                    if (ct.splits > 1 && mc * ct.splits > PARTIAL_FLOATS) continue;
-                    constexpr int REPS = 6;
-                    for (int rep = 0; rep <= REPS; ++rep) {
-                        if (rep == 1) SBGM_HIP(hipEventRecord(e0, st));
-                        if (launch_any(g, p, ct, st)) return 1;
-                    }
-                    SBGM_HIP(hipEventRecord(e1, st));
-                    SBGM_HIP(hipEventSynchronize(e1));
-                    float ms = 0.f;
-                    SBGM_HIP(hipEventElapsedTime(&ms, e0, e1));
-                    if (ms < best) { best = ms; best_t = ct; }
-                }
-            (void)hipEventDestroy(e0);
-            (void)hipEventDestroy(e1);
+            if (sbgm_tune_conv(g, p, partial, PARTIAL_FLOATS, st, &best_t)) return 1;
             tuned[key] = best_t;
         }
     }

@@ -148,6 +148,9 @@ int sbgm_launch_cfg_combine(float* out, const float* s_cond, const float* s_unco
 struct sbgm_assemble_args;
 int sbgm_launch_assemble_conditions(const sbgm_assemble_args& a, hipStream_t st);
 
+// ---- engine.hip: tile search for one convolution (used by the model's autotuner and by sbgm_conv2d_tune) -------------------
+int sbgm_tune_conv(const ConvGeom& g, const ConvParams& p, float* partial, size_t partial_floats, hipStream_t st, ConvTile* best);
+
 // ---- tiling.hip (full-domain tiles) -----------------------------------------------------------------------------------
 int sbgm_launch_extract_tiles(const float* dom, const int* origins, float* tiles, int T, int C, int Hd, int Wd, int th, int tw,
                               hipStream_t st);

@@ -367,9 +367,22 @@ def _sigma_of(fn) -> float:
 # --------------------------------------------------------------------------------------------------------------
 # VE-SDE schedule (reference score_unet.py:881-934): [B]-sized host-orchestrated math, plain tensor ops
 # --------------------------------------------------------------------------------------------------------------
+_SIGMA_CACHE = {}
+
+
+def _sigma_tensor(sigma: float, device) -> torch.Tensor:
+    """`torch.tensor(sigma, device=...)` of the reference (:893), built once per (value, device): the host->device copy
+    behind torch.tensor is not allowed while a stream is being captured into a graph"""
+    key = (float(sigma), str(device))
+    s = _SIGMA_CACHE.get(key)
+    if s is None:
+        s = _SIGMA_CACHE[key] = torch.tensor(float(sigma), dtype=torch.float32, device=device)
+    return s
+
+
 def marginal_prob_std(t: torch.Tensor, sigma: float, eps: float = 1e-5) -> torch.Tensor:
     t = t.to(dtype=torch.float32)
-    s = torch.tensor(sigma, dtype=t.dtype, device=t.device)
+    s = _sigma_tensor(sigma, t.device)
     return torch.clamp(torch.sqrt((torch.exp((2.0 * t) * torch.log(s)) - 1.0) / (2.0 * torch.log(s))), min=eps)
 
 

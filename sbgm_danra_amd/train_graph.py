@@ -31,10 +31,33 @@ def _pad_c(c):
     return 4 if c <= 4 else 8 if c <= 8 else (c + 15) // 16 * 16
 
 
+_TILES = {}            # conv geometry -> (tile_co, tile_px, splits, waves_per_tile, winograd bits), found by sbgm_conv2d_tune
+_SPLITK = {}           # device -> split-K scratch (16 Mi floats), shared by every convolution (stream-ordered)
+_SPLITK_FLOATS = 16 << 20
+
+
+def _splitk_ws(dev):
+    ws = _SPLITK.get(dev)
+    if ws is None:
+        ws = _SPLITK[dev] = torch.empty(_SPLITK_FLOATS, device=dev)
+    return ws
+
+
 def _conv_launch(x, packed, out, cs, cout, k, stride, pad, bias=None, res=None, tbias=None, in_dil=0, out_hw=(0, 0)):
+    """One convolution through the per-op C ABI.  The first time a geometry is seen (outside graph capture) the library
+    times its kernel / tile / split-K candidates on these very operands and the winner is reused from then on."""
     B, H, W, _ = x.shape
+    key = (B, H, W, cs, cout, k, stride, pad, in_dil, out_hw, bias is not None, res is not None, tbias is not None)
+    ws = _splitk_ws(x.device)
     a = N.ConvArgs(x.data_ptr(), packed.data_ptr(), out.data_ptr(), None, N.ptr(bias), N.ptr(tbias), N.ptr(res), B, H, W, cs, cout, k, k,
-                   stride, pad, N.NONE, 0, 0, 0, 0, 0, 0, in_dil, out_hw[0], out_hw[1], None, 0)
+                   stride, pad, N.NONE, 0, 0, 0, 0, 0, 0, in_dil, out_hw[0], out_hw[1], ws.data_ptr(), _SPLITK_FLOATS)
+    tile = _TILES.get(key)
+    if tile is None and cout % 32 == 0 and not torch.cuda.is_current_stream_capturing():
+        t6 = (C.c_int * 6)()
+        N.check(_L().sbgm_conv2d_tune(C.byref(a), t6, _st()))
+        tile = _TILES[key] = (t6[0], t6[1], t6[2], t6[3], t6[4] | (t6[5] << 1))
+    if tile is not None:
+        a.tile_co, a.tile_px, a.splits, a.waves_per_tile, a.winograd = tile
     N.check(_L().sbgm_conv2d_fwd(C.byref(a), _st()))
 
 
