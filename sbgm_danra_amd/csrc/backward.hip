@@ -42,16 +42,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
 #pragma unroll
         for (int j = 0; j < FCI; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    for (int p0 = p_begin; p0 < p_end; p0 += 4) {
-        const int p = p0 + kq;                                   // this lane's pixel (the MFMA k index)
-        f32x4 a = {0.f, 0.f, 0.f, 0.f};
-        float bv[FCI];
+    // operands of the 4-pixel group starting at p0 (this lane's pixel p0 + kq is the MFMA k index); zeros past the range / image
+    const int OHW = OH * OW;
+    auto load = [&](int p0, f32x4& a, float (&bv)[FCI]) {
+        const int p = p0 + kq;
+        a = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < FCI; ++j) bv[j] = 0.f;
         if (p < p_end) {
             a = *reinterpret_cast<const f32x4*>(dy + (size_t)p * Cout + co0 + 4 * r16);
-            const int b = p / (OH * OW);
-            const int rr = p - b * OH * OW;
+            const int b = p / OHW;
+            const int rr = p - b * OHW;
             const int oy = rr / OW, ox = rr - oy * OW;
             const int iy = oy * S - PAD + kh, ix = ox * S - PAD + kw;
             if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
@@ -61,10 +62,22 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
                     if (ci0 + 16 * j + r16 < Cs) bv[j] = xp[16 * j];
             }
         }
+    };
+    auto mma = [&](const f32x4& a, const float (&bv)[FCI]) {
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
             for (int j = 0; j < FCI; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bv[j], acc[i][j], 0, 0, 0);
+    };
+    // two register sets: the loads of the next group are in flight while the matrix pipe works on the current one
+    f32x4 a0, a1;
+    float b0[FCI], b1[FCI];
+    load(p_begin, a0, b0);
+    for (int p0 = p_begin; p0 < p_end; p0 += 8) {
+        load(p0 + 4, a1, b1);
+        mma(a0, b0);
+        load(p0 + 8, a0, b0);
+        mma(a1, b1);
     }
     // D_i[row][col]: row = 4*kq + reg -> channel co0 + 4*row + i ; col = r16 -> ci0 + 16j + r16
     float* base = dwp + ((size_t)tap * Cout) * Cs;
@@ -543,7 +556,7 @@ int sbgm_launch_conv_wgrad(const float* dy, const float* x, float* dw_oihw, floa
     const int OH = (H + 2 * PAD - KH) / S + 1, OW = (W + 2 * PAD - KW) / S + 1, M = B * OH * OW;
     const int fci = Cs % 64 == 0 ? 4 : (Cs % 32 == 0 ? 2 : 1);
     const int tiles = KH * KW * (Cout / 64) * ((Cs + 16 * fci - 1) / (16 * fci));
-    int splits = std::max(1, std::min((M + 63) / 64, (4096 + tiles - 1) / tiles));
+    int splits = std::max(1, std::min((M + 63) / 64, (4096 + tiles - 1) / tiles));   // measured: 1024 target waves is 14 % slower per step
     int pps = ((M + splits - 1) / splits + 3) / 4 * 4;
     splits = (M + pps - 1) / pps;
     const size_t n = (size_t)KH * KW * Cout * Cs;
