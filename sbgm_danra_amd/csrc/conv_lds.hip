@@ -18,7 +18,15 @@
 namespace {
 
 constexpr int TW = 16;          // tile width = one MFMA fragment of pixels
-constexpr int PWID = TW + 2;    // patch width
+constexpr int PWID = TW + 2;    // patch width (loaded columns)
+
+// LDS layout.  A pixel (or an output channel of the weight slab) owns 4 consecutive 16-byte slots, one per 4-channel quad.
+// ds_read_b128 is served in four fixed 16-lane groups that mix two k-quads and 8 + 8 fragment rows (MI355X_MICROARCH.md
+// §LDS); with the plain order quad = kq the 16 lanes of a group fall on 4-8 distinct slots of the 256-byte bank row
+// (2-way conflicts for the direct reads, 4-way for the Winograd column pairs; SQ_LDS_BANK_CONFLICT was 46 % of the LDS
+// cycles).  Rotating the quad by (index >> 1), plus an odd patch stride for the Winograd variant, makes every group hit 16
+// distinct slots (exhaustive check over all taps / column offsets).
+__device__ __forceinline__ int swz(int idx, int quad) { return idx * 4 + ((quad + (idx >> 1)) & 3); }
 
 template <int FCO, int FPX, bool WINO>
 __global__ __launch_bounds__(256) void conv3x3_lds_kernel(const ConvParams p) {
@@ -28,9 +36,10 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(const ConvParams p) {
     constexpr int NCO = 16 * FCO;
     constexpr int NTAP = WINO ? 12 : 9;
     constexpr int WQ = NTAP * NCO * 4;          // weight quads (16 B) per stage
-    constexpr int PQ = PH * PWID * 4;           // patch quads per stage
+    constexpr int PWS = WINO ? PWID + 1 : PWID; // patch row stride in LDS (odd for the Winograd column pairs)
+    constexpr int PQ = PH * PWID * 4;           // patch quads loaded per stage
     f32x4* wl = reinterpret_cast<f32x4*>(smem_raw);            // [tap][co][4 quads]
-    f32x4* pt = wl + WQ;                                        // [py][px][4 quads]
+    f32x4* pt = wl + WQ;                                        // [py][px (stride PWS)][4 quads, rotated]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -86,11 +95,16 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(const ConvParams p) {
     };
     auto stage_store = [&]() {
 #pragma unroll
-        for (int u = 0; u < WPT; ++u)
-            if (tid + 256 * u < WQ) wl[tid + 256 * u] = rw[u];
+        for (int u = 0; u < WPT; ++u) {
+            const int q = tid + 256 * u;                       // [tap][co][quad]: rotate the quad by the fragment row (co & 15) >> 1
+            if (q < WQ) wl[(q & ~3) + (((q & 3) + (((q >> 2) & 15) >> 1)) & 3)] = rw[u];
+        }
 #pragma unroll
-        for (int u = 0; u < PPT; ++u)
-            if (tid + 256 * u < PQ) pt[tid + 256 * u] = rp[u];
+        for (int u = 0; u < PPT; ++u) {
+            const int q = tid + 256 * u;
+            const int pix = q >> 2, py = pix / PWID, px = pix - py * PWID;
+            if (q < PQ) pt[py * PWS * 4 + swz(px, q & 3)] = rp[u];
+        }
     };
     stage_load(0);
     stage_store();
@@ -106,9 +120,9 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(const ConvParams p) {
                 for (int kw = 0; kw < 3; ++kw) {
                     f32x4 a[FCO], bb[FPX];
 #pragma unroll
-                    for (int i = 0; i < FCO; ++i) a[i] = wl[((kh * 3 + kw) * NCO + 16 * i + r16) * 4 + kq];
+                    for (int i = 0; i < FCO; ++i) a[i] = wl[((kh * 3 + kw) * NCO + 16 * i) * 4 + swz(r16, kq)];
 #pragma unroll
-                    for (int j = 0; j < FPX; ++j) bb[j] = pt[((wave * FPX + j + kh) * PWID + r16 + kw) * 4 + kq];
+                    for (int j = 0; j < FPX; ++j) bb[j] = pt[(wave * FPX + j + kh) * PWS * 4 + swz(r16 + kw, kq)];
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -126,15 +140,16 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(const ConvParams p) {
                 for (int j = 0; j < FPX; ++j) {
                     const int prow = wave * FPX * 2 + 2 * j + (r16 >> 3) + kh;     // patch row
                     const int pcol = 2 * (r16 & 7);                                   // patch col of d0 (= ox0 - 1 - (x0 - 1))
-                    const f32x4* src = pt + (prow * PWID + pcol) * 4 + kq;
-                    const f32x4 d0 = src[0], d1 = src[4], d2 = src[8], d3 = src[12];
+                    const f32x4* src = pt + prow * PWS * 4;
+                    const f32x4 d0 = src[swz(pcol, kq)], d1 = src[swz(pcol + 1, kq)], d2 = src[swz(pcol + 2, kq)],
+                                d3 = src[swz(pcol + 3, kq)];
                     v[0][j] = d0 - d2; v[1][j] = d1 + d2; v[2][j] = d2 - d1; v[3][j] = d1 - d3;
                 }
 #pragma unroll
                 for (int xi = 0; xi < 4; ++xi) {
                     f32x4 a[FCO];
 #pragma unroll
-                    for (int i = 0; i < FCO; ++i) a[i] = wl[((kh * 4 + xi) * NCO + 16 * i + r16) * 4 + kq];
+                    for (int i = 0; i < FCO; ++i) a[i] = wl[((kh * 4 + xi) * NCO + 16 * i) * 4 + swz(r16, kq)];
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
 #pragma unroll
@@ -244,7 +259,7 @@ int sbgm_launch_conv_lds(ConvParams p, const ConvTile& cfg, hipStream_t st) {
     const int TH = 4 * rows_per_wave;
     const int tiles = (p.W / 16) * ((p.H + TH - 1) / TH) * p.B * (p.Cout / (16 * cfg.fco));
     const int ntap = cfg.wino ? 12 : 9;
-    const size_t lds = ((size_t)ntap * 16 * cfg.fco * 4 + (size_t)(TH + 2) * 18 * 4) * 16;
+    const size_t lds = ((size_t)ntap * 16 * cfg.fco * 4 + (size_t)(TH + 2) * (cfg.wino ? 19 : 18) * 4) * 16;
     int rc = 1;
 #define SBGM_L(FC, FP, WN)                                                                                  \
     if (cfg.fco == FC && cfg.fpx == FP && (cfg.wino != 0) == WN) {                                            \
