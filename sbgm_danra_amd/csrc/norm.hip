@@ -88,14 +88,43 @@ __global__ __launch_bounds__(NORM_THREADS) void gn_partial_kernel(const float* _
     const int stripe = threadIdx.x / cq;
     const int p_begin = blockIdx.x * px_per_block;
     const int p_end = min(HW, p_begin + px_per_block);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
     if (stripe < lanes_px) {
-        f32x4 s = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
         const float* base = x + (size_t)b * HW * C + q * 4;
         for (int p = p_begin + stripe; p < p_end; p += lanes_px) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(base + (size_t)p * C);
             s += v;
             s2 += v * v;
         }
+    }
+    if ((cq & (cq - 1)) == 0 && cq <= NORM_THREADS) {
+        // power-of-two channel count: combine the stripes that share a channel quad with wavefront shuffles, park one fp32
+        // partial per (row, quad) in LDS with plain stores and finish in fp64 — no LDS atomics (they dominated this kernel)
+        float* part = reinterpret_cast<float*>(ssq + C);                 // [rows][cq][8]
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        for (int o = cq; o < 64; o <<= 1) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s[e] += __shfl_xor(s[e], o, 64); s2[e] += __shfl_xor(s2[e], o, 64); }
+        }
+        const int row = cq <= 64 ? wave : stripe;
+        const int rows = cq <= 64 ? NORM_THREADS / 64 : NORM_THREADS / cq;
+        if (cq > 64 || lane < cq) {
+            float* o = part + ((size_t)row * cq + q) * 8;
+            *reinterpret_cast<f32x4*>(o) = s;
+            *reinterpret_cast<f32x4*>(o + 4) = s2;
+        }
+        __syncthreads();
+        for (int c = threadIdx.x; c < C; c += NORM_THREADS) {
+            double a = 0.0, a2 = 0.0;
+            for (int r = 0; r < rows; ++r) {
+                const float* o = part + ((size_t)r * cq + (c >> 2)) * 8 + (c & 3);
+                a += (double)o[0];
+                a2 += (double)o[4];
+            }
+            ssum[c] = a;
+            ssq[c] = a2;
+        }
+    } else if (stripe < lanes_px) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             atomicAdd(&ssum[q * 4 + e], (double)s[e]);      // ds_add_f64
@@ -145,6 +174,33 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const float* __res
     const f32x4* xb = reinterpret_cast<const f32x4*>(x) + (size_t)b * per_sample;
     const f32x4* sb = skip ? reinterpret_cast<const f32x4*>(skip) + (size_t)b * per_sample : nullptr;
     f32x4* yb = reinterpret_cast<f32x4*>(y) + (size_t)b * per_sample;
+    if (256 % cq == 0) {
+        // fast path (C = 64 .. 1024 in powers of two): a thread keeps ONE channel quad for the whole sweep, so mean, rstd*gamma,
+        // beta and the time bias live in registers and the loop body is load - sub - fma - (add) - act - store: no index
+        // divisions, no LDS or parameter reads per element
+        const int c = (threadIdx.x % cq) * 4;
+        f32x4 mu, a, bt;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int g = (c + e) / cpg;
+            mu[e] = mr[2 * g];
+            a[e] = gamma ? mr[2 * g + 1] * gamma[c + e] : mr[2 * g + 1];
+            bt[e] = gamma ? beta[c + e] : 0.f;
+        }
+        if (tbias) bt += *reinterpret_cast<const f32x4*>(tbias + (size_t)b * C + c);
+        const size_t stride = (size_t)gridDim.x * blockDim.x;        // a multiple of cq, so the quad never changes
+        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_sample; i += stride) {
+            f32x4 v = (xb[i] - mu) * a;
+            if (sb) v += sb[i];
+            v += bt;
+            if (act != SBGM_ACT_NONE) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = sbgm_act(v[e], act);
+            }
+            yb[i] = v;
+        }
+        return;
+    }
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_sample; i += (size_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % cq) * 4;
         f32x4 v = xb[i];
@@ -252,8 +308,8 @@ int sbgm_launch_groupnorm(const float* x, float* y, const float* gamma, const fl
     int chunks = std::max(1, std::min(GN_MAX_CHUNKS, HW / (lanes_px * 16)));
     const int ppb = (HW + chunks - 1) / chunks;
     chunks = (HW + ppb - 1) / ppb;
-    hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, B), dim3(NORM_THREADS), 2 * C * sizeof(double), st, x, stats_ws, HW, C,
-                       G, ppb);
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, B), dim3(NORM_THREADS), 2 * C * sizeof(double) + 8192, st, x, stats_ws,
+                       HW, C, G, ppb);
     SBGM_LAUNCH_CHECK();
     const size_t per_sample = (size_t)HW * (C / 4);
     const int bx = (int)std::max<size_t>(1, std::min<size_t>((per_sample + 255) / 256, 2048 / std::max(1, B) + 1));
