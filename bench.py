@@ -307,7 +307,7 @@ def main():
 
     if rank == 0:
         value = B * a.steps * world / dt
-        line = {"metric": "denoising steps/sec (batch x SDE-steps/s) at 128x128", "value": value, "unit": "denoising steps/s",
+        line = {"metric": f"denoising steps/sec (batch x SDE-steps/s) at {HW}x{HW}", "value": value, "unit": "denoising steps/s",
                 "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                 "config": {"workload": f"{HW}x{HW} 1-cond->1-target (C_in=2), batch {B}/GPU, VE-SDE "
