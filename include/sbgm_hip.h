@@ -168,7 +168,8 @@ typedef struct sbgm_conv_args {
     int waves_per_tile;      /* in-workgroup split-K: 1, 2 or 4 waves share one tile; 0 = 1 */
     int winograd;            /* bit 0: Winograd F(2,3) weights/kernel (3x3/s1/p1; w_packed from sbgm_conv_wino_pack_weight;
                                 tile_px counts 32-pixel fragments: {4,1} {2,2} {2,1} {4,2});
-                                bit 1: LDS-staged kernel (W %% 16 == 0; tile_px = tile rows per wave, 2x that with bit 0) */
+                                bit 1: LDS-staged kernel (W %% 16 == 0; tile_px = tile rows per wave, 2x that with bit 0);
+                                bit 2 (with bit 1): two LDS stage buffers, one barrier per stage */
     int in_dil;              /* 0/1, or 2: read x through a zero-inserted grid (data gradient of a stride-2 conv) */
     int out_h, out_w;        /* explicit output size (required with in_dil = 2), else 0 */
     float* ws;
@@ -176,7 +177,7 @@ typedef struct sbgm_conv_args {
 } sbgm_conv_args;
 int sbgm_conv2d_fwd(const sbgm_conv_args* a, void* stream);
 /* Times the kernel / tile / split candidates for exactly this call (same operands; launches are idempotent; synchronises)
- * and writes the fastest as tile[6] = {tile_co, tile_px, splits, waves_per_tile, winograd bit 0, winograd bit 1}, the values
+ * and writes the fastest as tile[6] = {tile_co, tile_px, splits, waves_per_tile, winograd bit 0, LDS kernel: 0 off / 1 on (bit 1) / 2 double-buffered (bits 1+2)}, the values
  * to put into sbgm_conv_args.  Winograd candidates are skipped (they need the transformed weights); split-K candidates are
  * considered when a->ws is given.  Used by the training path, whose convolutions run op by op. */
 int sbgm_conv2d_tune(const sbgm_conv_args* a, int* tile, void* stream);

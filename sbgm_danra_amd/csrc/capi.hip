@@ -43,7 +43,7 @@ int sbgm_conv2d_fwd(const sbgm_conv_args* a, void* stream) {
     p.tbias_after_act = a->tbias_after_act;
     p.in_dil = a->in_dil; p.out_h = a->out_h; p.out_w = a->out_w;
     ConvTile t{a->tile_co ? a->tile_co : (a->Cout % 64 == 0 ? 4 : 2), a->tile_px ? a->tile_px : 2, a->splits ? a->splits : 1,
-               a->waves_per_tile ? a->waves_per_tile : 1, a->winograd & 1, (a->winograd >> 1) & 1};
+               a->waves_per_tile ? a->waves_per_tile : 1, a->winograd & 1, (a->winograd & 2) ? ((a->winograd & 4) ? 2 : 1) : 0};
     if (a->winograd & 2) {
         SBGM_CHECK(a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad == 1 && a->in_dil <= 1, "conv2d: the LDS path is 3x3 stride 1 pad 1 only");
         if (!a->tile_px) t.fpx = 1;

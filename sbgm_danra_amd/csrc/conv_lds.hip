@@ -28,7 +28,8 @@ constexpr int PWID = TW + 2;    // patch width (loaded columns)
 // distinct slots (exhaustive check over all taps / column offsets).
 __device__ __forceinline__ int swz(int idx, int quad) { return idx * 4 + ((quad + (idx >> 1)) & 3); }
 
-template <int FCO, int FPX, bool WINO>
+// DB: two LDS stage buffers -> one barrier per stage instead of two, and a stage's LDS stores overlap the other waves' MFMAs.
+template <int FCO, int FPX, bool WINO, bool DB>
 __global__ __launch_bounds__(256) void conv3x3_lds_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int TH = (WINO ? 8 : 4) * FPX;    // tile rows: 4 waves x FPX rows (Winograd: 2*FPX rows per wave)
@@ -38,6 +39,7 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(const ConvParams p) {
     constexpr int WQ = NTAP * NCO * 4;          // weight quads (16 B) per stage
     constexpr int PWS = WINO ? PWID + 1 : PWID; // patch row stride in LDS (odd for the Winograd column pairs)
     constexpr int PQ = PH * PWID * 4;           // patch quads loaded per stage
+    constexpr int STAGE_QUADS = WQ + PH * PWS * 4;
     f32x4* wl = reinterpret_cast<f32x4*>(smem_raw);            // [tap][co][4 quads]
     f32x4* pt = wl + WQ;                                        // [py][px (stride PWS)][4 quads, rotated]
 
@@ -93,24 +95,39 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(const ConvParams p) {
             rp[u] = buf_load4(xr, ok ? (uint32_t)(((b * p.H + iy) * p.W + ix) * p.Cs + cb * 16 + quad * 4) * 4u : 0x80000000u);
         }
     };
-    auto stage_store = [&]() {
+    f32x4* const wl0 = wl;
+    f32x4* const pt0 = pt;
+    auto stage_store = [&](int buf) {
+        f32x4* wd = wl0 + buf * STAGE_QUADS;
+        f32x4* pd = pt0 + buf * STAGE_QUADS;
 #pragma unroll
         for (int u = 0; u < WPT; ++u) {
             const int q = tid + 256 * u;                       // [tap][co][quad]: rotate the quad by the fragment row (co & 15) >> 1
-            if (q < WQ) wl[(q & ~3) + (((q & 3) + (((q >> 2) & 15) >> 1)) & 3)] = rw[u];
+            if (q < WQ) wd[(q & ~3) + (((q & 3) + (((q >> 2) & 15) >> 1)) & 3)] = rw[u];
         }
 #pragma unroll
         for (int u = 0; u < PPT; ++u) {
             const int q = tid + 256 * u;
             const int pix = q >> 2, py = pix / PWID, px = pix - py * PWID;
-            if (q < PQ) pt[py * PWS * 4 + swz(px, q & 3)] = rp[u];
+            if (q < PQ) pd[py * PWS * 4 + swz(px, q & 3)] = rp[u];
         }
     };
     stage_load(0);
-    stage_store();
+    stage_store(0);
+    if (DB && CB > 1) stage_load(1);
     for (int cb = 0; cb < CB; ++cb) {
-        if (cb + 1 < CB) stage_load(cb + 1);
-        __syncthreads();
+        if (!DB) {
+            if (cb + 1 < CB) stage_load(cb + 1);
+            __syncthreads();
+        } else {
+            __syncthreads();                     // stage cb is visible; every wave has finished stage cb-1 (the other buffer)
+            if (cb + 1 < CB) {
+                stage_store((cb + 1) & 1);
+                if (cb + 2 < CB) stage_load(cb + 2);
+            }
+            wl = wl0 + (cb & 1) * STAGE_QUADS;
+            pt = pt0 + (cb & 1) * STAGE_QUADS;
+        }
 
         // ---- sweep the taps out of LDS ------------------------------------------------------------------------------------
         if (!WINO) {
@@ -160,8 +177,10 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(const ConvParams p) {
                 }
             }
         }
-        __syncthreads();                         // every wave is done reading this stage
-        if (cb + 1 < CB) stage_store();
+        if (!DB) {
+            __syncthreads();                     // every wave is done reading this stage
+            if (cb + 1 < CB) stage_store(0);
+        }
     }
 
     // ---- epilogue ------------------------------------------------------------------------------------------------------------
@@ -259,18 +278,22 @@ int sbgm_launch_conv_lds(ConvParams p, const ConvTile& cfg, hipStream_t st) {
     const int TH = 4 * rows_per_wave;
     const int tiles = (p.W / 16) * ((p.H + TH - 1) / TH) * p.B * (p.Cout / (16 * cfg.fco));
     const int ntap = cfg.wino ? 12 : 9;
-    const size_t lds = ((size_t)ntap * 16 * cfg.fco * 4 + (size_t)(TH + 2) * (cfg.wino ? 19 : 18) * 4) * 16;
+    const bool db = cfg.lds == 2;                       // double-buffered stages
+    const size_t lds = ((size_t)ntap * 16 * cfg.fco * 4 + (size_t)(TH + 2) * (cfg.wino ? 19 : 18) * 4) * 16 * (db ? 2 : 1);
+    SBGM_CHECK(lds <= 160 * 1024, "conv_lds: tile needs %zu bytes of LDS", lds);
     int rc = 1;
-#define SBGM_L(FC, FP, WN)                                                                                  \
-    if (cfg.fco == FC && cfg.fpx == FP && (cfg.wino != 0) == WN) {                                            \
+#define SBGM_L2(FC, FP, WN, DBV)                                                                            \
+    if (cfg.fco == FC && cfg.fpx == FP && (cfg.wino != 0) == WN && db == DBV) {                               \
         if (lds > 64 * 1024)                                                                                  \
-            SBGM_HIP(hipFuncSetAttribute((const void*)conv3x3_lds_kernel<FC, FP, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((conv3x3_lds_kernel<FC, FP, WN>), dim3(tiles), dim3(256), lds, st, p);           \
+            SBGM_HIP(hipFuncSetAttribute((const void*)conv3x3_lds_kernel<FC, FP, WN, DBV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((conv3x3_lds_kernel<FC, FP, WN, DBV>), dim3(tiles), dim3(256), lds, st, p);      \
         rc = 0;                                                                                              \
     }
+#define SBGM_L(FC, FP, WN) SBGM_L2(FC, FP, WN, false) SBGM_L2(FC, FP, WN, true)
     SBGM_L(4, 1, false) SBGM_L(4, 2, false) SBGM_L(4, 4, false) SBGM_L(2, 2, false) SBGM_L(2, 4, false)
     SBGM_L(4, 1, true) SBGM_L(4, 2, true) SBGM_L(2, 1, true) SBGM_L(2, 2, true)
 #undef SBGM_L
+#undef SBGM_L2
     SBGM_CHECK(rc == 0, "conv_lds: no kernel for tile fco=%d fpx=%d wino=%d", cfg.fco, cfg.fpx, cfg.wino);
     SBGM_LAUNCH_CHECK();
     return 0;

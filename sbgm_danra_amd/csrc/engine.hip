@@ -404,15 +404,20 @@ int sbgm_tune_conv(const ConvGeom& g, const ConvParams& p, float* partial, size_
     }
     if (s1 && p.W % 16 == 0 && p.Cs % 16 == 0 && getenv("SBGM_NO_LDS_CONV") == nullptr) {
         const int dt[5][2] = {{4, 1}, {4, 2}, {4, 4}, {2, 2}, {2, 4}};
+        auto lds_bytes = [](int fco, int rows_per_wave, bool wino) {
+            return ((size_t)(wino ? 12 : 9) * 16 * fco * 4 + (size_t)(4 * rows_per_wave + 2) * (wino ? 19 : 18) * 4) * 16;
+        };
         for (auto& t : dt) {
             if (p.Cout % (16 * t[0]) || (p.proj_w && 16 * t[0] != p.Cout)) continue;
             cands.push_back(ConvTile{t[0], t[1], 1, 1, 0, 1});
+            if (2 * lds_bytes(t[0], t[1], false) <= 160 * 1024) cands.push_back(ConvTile{t[0], t[1], 1, 1, 0, 2});   // double-buffered
         }
         const int wt2[4][2] = {{4, 1}, {4, 2}, {2, 1}, {2, 2}};
         if (p.wp_wino)
             for (auto& t : wt2) {
                 if (p.Cout % (16 * t[0]) || (p.proj_w && 16 * t[0] != p.Cout)) continue;
                 cands.push_back(ConvTile{t[0], t[1], 1, 1, 1, 1});
+                if (2 * lds_bytes(t[0], 2 * t[1], true) <= 160 * 1024) cands.push_back(ConvTile{t[0], t[1], 1, 1, 1, 2});
             }
     }
     hipEvent_t e0, e1;
@@ -978,7 +983,7 @@ int sbgm_model_autotune(sbgm_model* m, int B, int H, int W, void* stream) {
 extern "C++" {
 static std::string conv_kernel_name(const sbgm_model::ConvRec& r) {
     char b[96];
-    if (r.t.lds) snprintf(b, sizeof b, "conv3x3_lds_kernel<%d; %d; %s>", r.t.fco, r.t.fpx, r.t.wino ? "true" : "false");
+    if (r.t.lds) snprintf(b, sizeof b, "conv3x3_lds_kernel<%d; %d; %s; %s>", r.t.fco, r.t.fpx, r.t.wino ? "true" : "false", r.t.lds == 2 ? "true" : "false");
     else if (r.t.wino) snprintf(b, sizeof b, "conv3x3_wino_kernel<%d; %d; %d>", r.t.fco, r.t.fpx, r.t.ws);
     else snprintf(b, sizeof b, "conv_igemm_kernel<%d; %d; %d; %d; %d; %d; %d; %d>", r.g.kh, r.g.kw, r.g.stride, r.g.pad, r.t.fco,
                   r.t.fpx, r.Cs >= 16 ? 0 : r.Cs, r.t.ws);
@@ -1018,7 +1023,7 @@ int sbgm_model_tune_load(sbgm_model* m, const char* path) {
                              &k.Cs, &k.Cout, &k.proj, &t[0], &t[1], &t[2], &t[3], &t[4], &t[5]);
         // the launchers reject tiles they do not instantiate; here only the ranges that index memory are checked
         const bool ok = n == 16 && (t[0] == 1 || t[0] == 2 || t[0] == 4) && (t[1] == 1 || t[1] == 2 || t[1] == 4) && t[2] >= 1 &&
-                        t[2] <= 64 && (t[3] == 1 || t[3] == 2 || t[3] == 4) && (t[4] | 1) == 1 && (t[5] | 1) == 1 &&
+                        t[2] <= 64 && (t[3] == 1 || t[3] == 2 || t[3] == 4) && (t[4] | 1) == 1 && t[5] >= 0 && t[5] <= 2 &&
                         k.Cout % (16 * t[0]) == 0;
         if (!ok) {
             fclose(f);

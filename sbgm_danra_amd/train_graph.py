@@ -55,7 +55,7 @@ def _conv_launch(x, packed, out, cs, cout, k, stride, pad, bias=None, res=None, 
     if tile is None and cout % 32 == 0 and not torch.cuda.is_current_stream_capturing():
         t6 = (C.c_int * 6)()
         N.check(_L().sbgm_conv2d_tune(C.byref(a), t6, _st()))
-        tile = _TILES[key] = (t6[0], t6[1], t6[2], t6[3], t6[4] | (t6[5] << 1))
+        tile = _TILES[key] = (t6[0], t6[1], t6[2], t6[3], t6[4] | (2 if t6[5] else 0) | (4 if t6[5] == 2 else 0))
     if tile is not None:
         a.tile_co, a.tile_px, a.splits, a.waves_per_tile, a.winograd = tile
     N.check(_L().sbgm_conv2d_fwd(C.byref(a), _st()))
