@@ -185,6 +185,10 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(const ConvParams p) {
 
     // ---- epilogue ------------------------------------------------------------------------------------------------------------
     const int hw = p.H * p.W;
+    const bool want_stats = p.gn_stats != nullptr;          // uniform
+    f32x4 gs[FCO], gs2[FCO];                                // this lane's sum / sum of squares of its outputs, per channel
+#pragma unroll
+    for (int i = 0; i < FCO; ++i) { gs[i] = f32x4{0.f, 0.f, 0.f, 0.f}; gs2[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     if (!WINO) {
 #pragma unroll
         for (int j = 0; j < FPX; ++j) {
@@ -211,7 +215,10 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(const ConvParams p) {
                 }
             } else if (ok) {
 #pragma unroll
-                for (int i = 0; i < FCO; ++i) *reinterpret_cast<f32x4*>(p.out + (size_t)m * p.Cout + co0 + 16 * i + 4 * kq) = y[i];
+                for (int i = 0; i < FCO; ++i) {
+                    *reinterpret_cast<f32x4*>(p.out + (size_t)m * p.Cout + co0 + 16 * i + 4 * kq) = y[i];
+                    if (want_stats) { gs[i] += y[i]; gs2[i] += y[i] * y[i]; }
+                }
             }
         }
     } else {
@@ -251,14 +258,67 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(const ConvParams p) {
                     const int co = co0 + 16 * i + 4 * kq;
                     *reinterpret_cast<f32x4*>(p.out + (size_t)m * p.Cout + co) = y0v[i];
                     *reinterpret_cast<f32x4*>(p.out + ((size_t)m + 1) * p.Cout + co) = y1v[i];
+                    if (want_stats) { gs[i] += y0v[i] + y1v[i]; gs2[i] += y0v[i] * y0v[i] + y1v[i] * y1v[i]; }
                 }
             }
         }
     }
     (void)hw;
+    if (want_stats) {
+        // GroupNorm statistics of this tile, deterministic: pixel lanes by shuffles, the 4 waves through LDS (fixed order), the
+        // channels of a group in fp64; one plain store per (group, tile) in the layout groupnorm_apply_kernel reduces.
+#pragma unroll
+        for (int i = 0; i < FCO; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int o = 1; o < 16; o <<= 1) {
+                    gs[i][e] += __shfl_xor(gs[i][e], o, 64);
+                    gs2[i][e] += __shfl_xor(gs2[i][e], o, 64);
+                }
+        __syncthreads();                                   // the stage buffers are free now
+        float* red = reinterpret_cast<float*>(smem_raw);    // [wave][NCO][2]
+        if (r16 == 0) {
+#pragma unroll
+            for (int i = 0; i < FCO; ++i)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    red[((wave * NCO) + 16 * i + 4 * kq + e) * 2] = gs[i][e];
+                    red[((wave * NCO) + 16 * i + 4 * kq + e) * 2 + 1] = gs2[i][e];
+                }
+        }
+        __syncthreads();
+        const int G = p.gn_groups, cpg = p.Cout / G;
+        const int sub = cpg > NCO ? cpg / NCO : 1;          // tiles' channel slices per group
+        const int ngrp = cpg > NCO ? 1 : NCO / cpg;         // whole groups inside this slice
+        const int span = cpg > NCO ? NCO : cpg;             // channels of one group inside this slice
+        if (tid < ngrp) {
+            double a = 0.0, a2 = 0.0;
+            for (int c = tid * span; c < (tid + 1) * span; ++c)
+                for (int w = 0; w < 4; ++w) {
+                    a += (double)red[(w * NCO + c) * 2];
+                    a2 += (double)red[(w * NCO + c) * 2 + 1];
+                }
+            const int chunks = tiles_x * tiles_y * sub;
+            const int chunk = (ty * tiles_x + tx) * sub + (co_tile % sub);
+            const int g = co0 / cpg + tid;
+            double* o = p.gn_stats + (((size_t)b * chunks + chunk) * G + g) * 2;
+            o[0] = a;
+            o[1] = a2;
+        }
+    }
 }
 
 }  // namespace
+
+int sbgm_conv_lds_gn_chunks(const ConvParams& p, const ConvTile& cfg) {
+    if (!cfg.lds || p.gn_groups <= 0 || p.Cout % p.gn_groups || p.proj_w) return 0;
+    const int nco = 16 * cfg.fco, cpg = p.Cout / p.gn_groups;
+    if (cpg > nco ? cpg % nco != 0 : nco % cpg != 0) return 0;
+    const int TH = 4 * (cfg.wino ? 2 * cfg.fpx : cfg.fpx);
+    const int chunks = (p.W / 16) * ((p.H + TH - 1) / TH) * (cpg > nco ? cpg / nco : 1);
+    return chunks <= 64 ? chunks : 0;
+}
 
 // cfg: fco in {2,4}; fpx = tile rows per wave (direct: 1,2,4 -> tile 4/8/16 rows; Winograd: rows per wave = 2*fpx);
 // cfg.wino selects the Winograd slab (p.wp must then be the Winograd pack).  W must be a multiple of 16.
@@ -268,6 +328,7 @@ int sbgm_launch_conv_lds(ConvParams p, const ConvTile& cfg, hipStream_t st) {
     SBGM_CHECK(p.act == SBGM_ACT_NONE || p.act == SBGM_ACT_RELU || p.act == SBGM_ACT_GELU, "conv_lds: act=%d does not fuse", p.act);
     SBGM_CHECK((size_t)p.B * p.H * p.W * p.Cs * 4 < (1ull << 31), "conv_lds: input tensor exceeds 2 GiB buffer window");
     SBGM_CHECK(p.proj_w == nullptr || (p.Cout == 16 * cfg.fco && p.proj_out != nullptr), "conv_lds: tap projection needs one co tile");
+    if (p.gn_stats && sbgm_conv_lds_gn_chunks(p, cfg) == 0) p.gn_stats = nullptr;      // this tile cannot produce them
     p.OH = p.H; p.OW = p.W;
     p.M = p.B * p.H * p.W;
     p.cb_per_tap = p.Cs / 16;

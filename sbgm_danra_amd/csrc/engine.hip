@@ -79,6 +79,7 @@ struct sbgm_model {
     StepScalars* d_table = nullptr;
     int table_cap = 0;
     std::map<ConvOpKey, ConvTile> tuned;
+    ConvTile last_tile{};                   // tile of the most recent conv() (tells the caller whether GroupNorm statistics were fused)
     bool tuning = false;
     struct ConvRec { ConvGeom g; int B, H, W, Cs, Cout, M, nsteps; ConvTile t; double flops; hipEvent_t e0, e1; float ms; };
     std::vector<ConvRec>* prof = nullptr;   // when set, conv() brackets every launch with events
@@ -459,6 +460,7 @@ int sbgm_model::conv(const ConvGeom& g, ConvParams p, hipStream_t st) {
     }
     ConvTile ct = pick_tile(g, p);
     if (ct.splits > 1 && mc * ct.splits > PARTIAL_FLOATS) ct.splits = (int)std::max<size_t>(1, PARTIAL_FLOATS / mc);
+    last_tile = ct;
     if (!prof) return launch_any(g, p, ct, st);
     ConvRec r{g, p.B, p.H, p.W, p.Cs, p.Cout, p.B * OH * OW, sbgm_conv_nsteps(g.kh, g.kw, p.Cs), ct, 0.0, nullptr, nullptr, 0.f};
     // algorithmic FLOPs: 2 * M * Cout * (KH*KW*Cin_real); Cs may be padded (only the stem conv), count real K there
@@ -637,6 +639,7 @@ int sbgm_model::forward(const float* x, const float* t, const int64_t* y, const 
         float* a = wsalloc((size_t)B * oh * ow * d.cin);
         if (!a) return 1;
         ConvParams p{};
+        int gn1_chunks = 0;
         if (cfg.decoder_transpose) {                 // ConvTranspose2d: 1x1 conv to 4*cin phase-major channels, then depth -> space
             p.x = cur; p.wp = d.up.w->dev; p.out = up; p.bias = d.up.b->dev; p.B = B; p.H = ch; p.W = cw_; p.Cs = d.cin; p.Cout = 4 * d.cin;
             if (conv(ConvGeom{1, 1, 1, 0}, p, st)) return 1;
@@ -646,16 +649,26 @@ int sbgm_model::forward(const float* x, const float* t, const int64_t* y, const 
         } else {
             if (sbgm_launch_upsample2x(cur, up, B, ch, cw_, d.cin, st)) return 1;
             p.x = up; p.wp = d.up.w->dev; p.wp_wino = d.up.w->dev_wino; p.out = a; p.bias = d.up.b->dev; p.B = B; p.H = oh; p.W = ow; p.Cs = d.cin; p.Cout = d.cin;
+            p.gn_stats = stats; p.gn_groups = groups(d.cin);        // GroupNorm statistics in the epilogue when the LDS kernel runs
             if (conv(ConvGeom{3, 3, 1, 1}, p, st)) return 1;
+            gn1_chunks = sbgm_conv_lds_gn_chunks(p, last_tile);
         }
-        if (sbgm_launch_groupnorm(a, a, d.n1g ? d.n1g->dev : nullptr, d.n1b ? d.n1b->dev : nullptr, nullptr, nullptr,
-                                  SBGM_ACT_NONE, B, oh * ow, d.cin, groups(d.cin), GN_EPS, stats, st)) return 1;
+        if (gn1_chunks > 0) {
+            if (sbgm_launch_groupnorm_apply(a, a, d.n1g ? d.n1g->dev : nullptr, d.n1b ? d.n1b->dev : nullptr, nullptr, nullptr,
+                                            SBGM_ACT_NONE, B, oh * ow, d.cin, groups(d.cin), GN_EPS, stats, gn1_chunks, st)) return 1;
+        } else if (sbgm_launch_groupnorm(a, a, d.n1g ? d.n1g->dev : nullptr, d.n1b ? d.n1b->dev : nullptr, nullptr, nullptr,
+                                         SBGM_ACT_NONE, B, oh * ow, d.cin, groups(d.cin), GN_EPS, stats, st)) return 1;
         float* c2 = wsalloc((size_t)B * oh * ow * d.cout);
         if (!c2) return 1;
         p.x = a; p.wp = d.conv.w->dev; p.wp_wino = d.conv.w->dev_wino; p.out = c2; p.bias = d.conv.b->dev; p.Cout = d.cout;
+        p.gn_stats = stats; p.gn_groups = groups(d.cout);
         if (conv(ConvGeom{3, 3, 1, 1}, p, st)) return 1;
-        if (sbgm_launch_groupnorm(c2, c2, d.n2g ? d.n2g->dev : nullptr, d.n2b ? d.n2b->dev : nullptr, fm[3 - i], tb[5 + i],
-                                  cfg.decoder_activation, B, oh * ow, d.cout, groups(d.cout), GN_EPS, stats, st)) return 1;
+        const int gn2_chunks = sbgm_conv_lds_gn_chunks(p, last_tile);
+        if (gn2_chunks > 0) {
+            if (sbgm_launch_groupnorm_apply(c2, c2, d.n2g ? d.n2g->dev : nullptr, d.n2b ? d.n2b->dev : nullptr, fm[3 - i], tb[5 + i],
+                                            cfg.decoder_activation, B, oh * ow, d.cout, groups(d.cout), GN_EPS, stats, gn2_chunks, st)) return 1;
+        } else if (sbgm_launch_groupnorm(c2, c2, d.n2g ? d.n2g->dev : nullptr, d.n2b ? d.n2b->dev : nullptr, fm[3 - i], tb[5 + i],
+                                         cfg.decoder_activation, B, oh * ow, d.cout, groups(d.cout), GN_EPS, stats, st)) return 1;
         if (d.has_attn && attention(d.attn, c2, B, oh * ow, st)) return 1;
         cur = c2; ch = oh; cw_ = ow;
     }

@@ -28,6 +28,9 @@ struct ConvParams {
     const float* proj_w;  // [9][Cout] or null: fuse the following 3x3 Cout=1 conv's per-tap channel dot products
     float* proj_out;      // [9][M] planar tap sums (then `out` is not written)
     const float* wp_wino; // host-side only: Winograd-packed copy of the weights (3x3 stride-1 layers), or null
+    double* gn_stats;     // conv_lds only, or null: per-workgroup GroupNorm partial sums of the OUTPUT (sum, sum of squares per
+                          // group) in the [b][chunk][G][2] layout groupnorm_apply reads -> no separate statistics pass
+    int gn_groups;        // G of that GroupNorm (channels per group must divide or be a multiple of the tile's channel slice)
     int in_dil;           // 1, or 2: read the input through a zero-inserted grid (data-gradient of a stride-2 conv)
     int out_h, out_w;     // explicit output size (required with in_dil == 2), else 0
     // filled by sbgm_launch_conv:
@@ -48,6 +51,8 @@ int sbgm_launch_conv_wino(ConvParams p, const ConvTile& cfg, hipStream_t st);   
 
 // ---- conv_lds.hip: 3x3 stride-1 pad-1 convolution with LDS-staged halo patch + weight slab (direct or Winograd) -----------
 int sbgm_launch_conv_lds(ConvParams p, const ConvTile& cfg, hipStream_t st);
+// chunks per sample the launch above writes into p.gn_stats for this tile, or 0 if that tile cannot produce them
+int sbgm_conv_lds_gn_chunks(const ConvParams& p, const ConvTile& cfg);
 
 // ---- pointwise.hip ---------------------------------------------------------------------------------
 struct PackSrc {
@@ -98,6 +103,10 @@ int sbgm_launch_pack_cout1_weight(const float* w_oihw, float* w_tap_c, int C, hi
 // ---- norm.hip ------------------------------------------------------------------------------------------
 // GroupNorm / InstanceNorm over NHWC.  stats_ws: groupnorm needs 16*64*B*G bytes (partial sums per pixel chunk);
 // batchnorm needs 24*C bytes (zeroed by the launcher).
+// second half of sbgm_launch_groupnorm only: the statistics were already written (by a convolution epilogue) as `chunks` partials
+int sbgm_launch_groupnorm_apply(const float* x, float* y, const float* gamma, const float* beta, const float* skip, const float* tbias,
+                                int act, int B, int HW, int C, int G, float eps, const double* stats, int chunks, hipStream_t st,
+                                float* mr_out = nullptr);
 int sbgm_launch_groupnorm(const float* x, float* y, const float* gamma, const float* beta, const float* skip,
                           const float* tbias, int act, int B, int HW, int C, int G, float eps, double* stats_ws,
                           hipStream_t st, float* mr_out = nullptr);   // mr_out: [B][G][2] (mean, rstd) kept for backward

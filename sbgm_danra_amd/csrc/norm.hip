@@ -297,6 +297,19 @@ inline int stream_blocks(size_t work_items) { return (int)std::min<size_t>((work
 
 }  // namespace
 
+int sbgm_launch_groupnorm_apply(const float* x, float* y, const float* gamma, const float* beta, const float* skip, const float* tbias,
+                                int act, int B, int HW, int C, int G, float eps, const double* stats, int chunks, hipStream_t st,
+                                float* mr_out) {
+    SBGM_CHECK(C % 4 == 0 && C <= 1024 && C % G == 0 && chunks >= 1 && chunks <= GN_MAX_CHUNKS, "groupnorm_apply: C=%d G=%d chunks=%d", C, G,
+               chunks);
+    const size_t per_sample = (size_t)HW * (C / 4);
+    const int bx = (int)std::max<size_t>(1, std::min<size_t>((per_sample + 255) / 256, 2048 / std::max(1, B) + 1));
+    hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(bx, B), dim3(256), 2 * G * sizeof(float), st, x, y, gamma, beta, skip, tbias,
+                       act, HW, C, G, chunks, eps, stats, mr_out);
+    SBGM_LAUNCH_CHECK();
+    return 0;
+}
+
 int sbgm_launch_groupnorm(const float* x, float* y, const float* gamma, const float* beta, const float* skip,
                           const float* tbias, int act, int B, int HW, int C, int G, float eps, double* stats_ws,
                           hipStream_t st, float* mr_out) {
