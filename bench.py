@@ -273,6 +273,9 @@ def main():
                     "gflop_per_launch": v["gflop"] / v["launches"], "tflops": v["gflop"] / v["ms"],
                     "alg_bytes_per_launch": v["bytes"] / v["launches"]}
                    for n, v in sorted(per.items(), key=lambda kv: -kv[1]["ms"])]
+        for k in kernels:        # Winograd F(2,3) instantiations execute 2/3 of the algorithmic (direct-convolution) FLOPs as MFMAs
+            wino = "wino_kernel" in k["kernel"] or ("lds_kernel" in k["kernel"] and k["kernel"].split(",")[2].strip() == "true")
+            k["executed_flop_ratio"] = 2.0 / 3.0 if wino else 1.0
         dom = kernels[0]
         # HBM-side traffic of that kernel: PMC counters cannot be read from inside this process; they come from the
         # separately collected rocprofv3 passes (tools/collect_profiles.sh -> profiles/r01_pmc_traffic.json), if committed
@@ -293,6 +296,10 @@ def main():
         roof = {"bound": "mfma", "kernel": dom["kernel"], "launches_per_eval": dom["launches"], "avg_launch_us": dom["avg_us"],
                 "gflop_per_launch": dom["gflop_per_launch"],
                 "achieved": dom["tflops"], "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_FP32_TFLOPS,
+                # `achieved` counts the algorithmic (direct-convolution) FLOPs of SURVEY 8d; a Winograd F(2,3) kernel issues 2/3 of
+                # them, so the matrix pipe itself is busy for about frac * executed_flop_ratio of the time
+                "executed_flop_ratio": dom["executed_flop_ratio"],
+                "mfma_pipe_frac": dom["tflops"] * dom["executed_flop_ratio"] / PEAK_FP32_TFLOPS,
                 "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
                 "alg_bytes_per_launch": dom["alg_bytes_per_launch"],
                 "conv_family": {"launches": n_conv, "ms_per_eval": ms_conv, "gflop_per_eval": fl_conv * 1e-9, "achieved": ach,
