@@ -173,6 +173,51 @@ def train_bench(a):
         dist.destroy_process_group()
 
 
+def domain_bench(a):
+    """BASELINE configs[4]: one 589x789 field as 12 overlapping 256x256 tiles (halo 32), predictor-corrector sampling, tiles
+    sharded over the ranks (one all-reduce of the finished tiles before the blend).  Secondary line: not the headline."""
+    import torch.distributed as dist
+    import sbgm_danra_amd as S
+    from sbgm_danra_amd import parallel
+    from sbgm_danra_amd.tiling import FullDomainTiler
+    rank, world, local = parallel.init_distributed()
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    net = build_model(dev)
+    tiler = FullDomainTiler((589, 789), 256, 32, device=dev)
+    mine = len(range(len(tiler))[rank::world])
+    if not a.no_autotune:
+        net.autotune(mine, 256, 256, cond_channels=(0, 0, 1), cache=a.tune_cache)
+    g = torch.Generator().manual_seed(42)
+    cond = torch.randn(1, 589, 789, generator=g).to(dev)
+    run = lambda n: tiler.sample(net, S.pc_sampler, S.marginal_prob_std_fn, S.diffusion_coeff_fn, num_steps=n, cond_img=cond, seed=7)   # noqa: E731
+    run(max(2, a.warmup))
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = run(a.steps)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert out.shape == (1, 589, 789) and torch.isfinite(out).all()
+    if world > 1:
+        tt = torch.tensor([dt], device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    if rank == 0:
+        print(json.dumps({"metric": "denoising steps/sec on the full 589x789 domain (tiles x SDE-steps/s)", "value": len(tiler) * a.steps / dt,
+                          "unit": "tile denoising steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                          "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                          "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": f"589x789 domain, {len(tiler)} tiles of 256x256 (halo 32), predictor-corrector, "
+                                                 f"{a.steps} steps, tiles sharded over {world} rank(s), domain-keyed noise, normalised ramp blend",
+                                     "seconds_per_field": dt, "tiles": len(tiler)}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -187,11 +232,14 @@ def main():
     ap.add_argument("--tune-cache", default=None, help="tile-table file: loaded when present, else written after autotuning "
                                                        "(lets the rocprofv3 passes replay exactly the benchmarked kernels)")
     ap.add_argument("--profile-csv", default=None, help="write the per-convolution event timings here")
-    ap.add_argument("--mode", choices=["sample", "train"], default="sample",
-                    help="sample = BASELINE configs[1] (the headline metric); train = configs[2] optimizer steps (secondary line)")
+    ap.add_argument("--mode", choices=["sample", "train", "domain"], default="sample",
+                    help="sample = BASELINE configs[1] (the headline metric); train = configs[2] optimizer steps; domain = "
+                         "configs[4] full-domain tiled sampling (secondary lines)")
     a = ap.parse_args()
     if a.mode == "train":
         return train_bench(a)
+    if a.mode == "domain":
+        return domain_bench(a)
 
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
