@@ -181,6 +181,19 @@ int sbgm_conv2d_fwd(const sbgm_conv_args* a, void* stream);
  * to put into sbgm_conv_args.  Winograd candidates are skipped (they need the transformed weights); split-K candidates are
  * considered when a->ws is given.  Used by the training path, whose convolutions run op by op. */
 int sbgm_conv2d_tune(const sbgm_conv_args* a, int* tile, void* stream);
+/* Pack many convolution weights in one launch.  desc: DEVICE array of n descriptors; block_begin = exclusive prefix of
+ * ceil(nsteps*Cout*16 / 256) over the descriptors, total_blocks = its total (nsteps from sbgm_conv_packed_numel / (Cout*16)).
+ * transposed != 0 packs the data-gradient operator: then Cout/Cin are the TRANSPOSED sizes (Cout = forward Cin, Cin = forward
+ * Cout) and cs is the padded forward Cout, exactly as sbgm_conv_pack_weight_dgrad does for one weight. */
+typedef struct sbgm_pack_desc {
+    const float* src;      /* OIHW */
+    float* dst;            /* packed [nsteps][Cout][16] */
+    int Cout, Cin, KH, KW, cs, nsteps, transposed, block_begin;
+} sbgm_pack_desc;
+int sbgm_conv_pack_weights_batched(const sbgm_pack_desc* desc_dev, int n, int total_blocks, void* stream);
+/* Process-wide switch for the backward launchers (sbgm_conv2d_wgrad, sbgm_groupnorm_bwd, sbgm_batchnorm_bwd): 1 = the caller
+ * hands in already-zeroed scratch and the launchers skip their own memsets.  Returns the previous value. */
+int sbgm_set_scratch_prezeroed(int on);
 /* Winograd F(2,3)-along-rows weight transform for 3x3 kernels: OIHW -> U[kh][c/16][xi][Cout][16] */
 int64_t sbgm_conv_wino_packed_numel(int Cout, int c_pad);
 int sbgm_conv_wino_pack_weight(const float* w_oihw, float* packed, int Cout, int Cin, int c_pad, void* stream);

@@ -40,6 +40,11 @@ class AssembleArgs(C.Structure):
                 ("lsm_out", _vp), ("topo_out", _vp), ("y_out", _vp)]
 
 
+class PackDesc(C.Structure):
+    _fields_ = [("src", _vp), ("dst", _vp), ("Cout", _i), ("Cin", _i), ("KH", _i), ("KW", _i), ("cs", _i), ("nsteps", _i),
+                ("transposed", _i), ("block_begin", _i)]
+
+
 class Profile(C.Structure):
     _fields_ = [("ms_total_with_events", _f), ("ms_conv", _f), ("ms_conv_max", _f), ("flops_conv", C.c_double),
                 ("flops_conv_max", C.c_double), ("n_conv", _i)]
@@ -90,6 +95,8 @@ SIGNATURES = {
     "sbgm_conv_pack_weight": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sbgm_conv2d_fwd": (_i, [C.POINTER(ConvArgs), _vp]),
     "sbgm_conv2d_tune": (_i, [C.POINTER(ConvArgs), C.POINTER(C.c_int), _vp]),
+    "sbgm_conv_pack_weights_batched": (_i, [_vp, _i, _i, _vp]),
+    "sbgm_set_scratch_prezeroed": (_i, [_i]),
     "sbgm_conv_wino_packed_numel": (_i64, [_i, _i]),
     "sbgm_conv_wino_pack_weight": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "sbgm_upsample2x_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),

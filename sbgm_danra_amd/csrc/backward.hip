@@ -6,6 +6,8 @@
 #include "common.h"
 #include "kernels.h"
 
+int sbgm_scratch_prezeroed = 0;
+
 namespace {
 
 inline int stream_blocks(size_t n, int cap = 2048) { return (int)std::min<size_t>((n + 255) / 256, (size_t)cap); }
@@ -56,6 +58,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
             const int oy = rr / OW, ox = rr - oy * OW;
             const int iy = oy * S - PAD + kh, ix = ox * S - PAD + kw;
             if ((unsigned)iy < (unsigned)H && (unsigned)ix < (unsigned)W) {
+                // (a 16-byte x load per lane was measured: the lane->channel map it forces makes the epilogue's atomics strided
+                //  and the step 30 % slower; the dword loads keep every atomic instruction on 64 contiguous bytes per row)
                 const float* xp = x + (((size_t)b * H + iy) * W + ix) * Cs + ci0 + r16;
 #pragma unroll
                 for (int j = 0; j < FCI; ++j)
@@ -560,7 +564,7 @@ int sbgm_launch_conv_wgrad(const float* dy, const float* x, float* dw_oihw, floa
     int pps = ((M + splits - 1) / splits + 3) / 4 * 4;
     splits = (M + pps - 1) / pps;
     const size_t n = (size_t)KH * KW * Cout * Cs;
-    SBGM_HIP(hipMemsetAsync(dwp_ws, 0, n * 4, st));
+    if (!sbgm_scratch_prezeroed) SBGM_HIP(hipMemsetAsync(dwp_ws, 0, n * 4, st));
     dim3 grid((tiles + 3) / 4, splits);
 #define SBGM_WG(F) hipLaunchKernelGGL(conv_wgrad_kernel<F>, grid, dim3(256), 0, st, dy, x, dwp_ws, B, H, W, Cs, OH, OW, Cout, KH, KW, S, PAD, pps)
     if (fci == 4) SBGM_WG(4); else if (fci == 2) SBGM_WG(2); else SBGM_WG(1);
@@ -592,7 +596,7 @@ int sbgm_launch_samplesum(const float* x, float* out, int B, int HW, int C, hipS
 
 static int norm_bwd(bool bn, NormBwdArgs a, float* dgamma, float* dbeta, float* dtbias, hipStream_t st) {
     SBGM_CHECK(a.C % 4 == 0 && a.C <= 1024, "norm_bwd: C=%d unsupported", a.C);
-    SBGM_HIP(hipMemsetAsync(a.s12, 0, (size_t)a.B * a.C * 2 * 4, st));
+    if (!sbgm_scratch_prezeroed) SBGM_HIP(hipMemsetAsync(a.s12, 0, (size_t)a.B * a.C * 2 * 4, st));
     const int lanes_px = std::max(1, 256 / (a.C / 4));
     int chunks = std::max(1, std::min(64, a.HW / (lanes_px * 16)));
     const int ppb = (a.HW + chunks - 1) / chunks;

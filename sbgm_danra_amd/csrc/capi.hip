@@ -63,6 +63,15 @@ int sbgm_conv2d_fwd(const sbgm_conv_args* a, void* stream) {
     return sbgm_launch_conv(ConvGeom{a->KH, a->KW, a->stride, a->pad}, p, t, a->ws, ST);
 }
 
+int sbgm_conv_pack_weights_batched(const sbgm_pack_desc* desc_dev, int n, int total_blocks, void* stream) {
+    return sbgm_launch_pack_conv_weights_batched(desc_dev, n, total_blocks, ST);
+}
+int sbgm_set_scratch_prezeroed(int on) {
+    const int prev = sbgm_scratch_prezeroed;
+    sbgm_scratch_prezeroed = on ? 1 : 0;
+    return prev;
+}
+
 int sbgm_conv2d_tune(const sbgm_conv_args* a, int* tile, void* stream) {
     SBGM_CHECK(a && tile && a->x && a->w_packed && a->out, "conv2d_tune: null argument");
     SBGM_CHECK(a->Cout % 32 == 0, "conv2d_tune: Cout=%d must be a multiple of 32", a->Cout);

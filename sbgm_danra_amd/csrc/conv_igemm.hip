@@ -19,6 +19,7 @@
 // accumulators through LDS before the epilogue (in-workgroup split-K: more waves per SIMD to hide the operand
 // latency, no extra launch, no global traffic), and, for the tiniest layers, split-K over gridDim.y followed by
 // splitk_reduce_epilogue.
+#include "../../include/sbgm_hip.h"
 #include "common.h"
 #include "kernels.h"
 #include "conv_common.h"
@@ -275,30 +276,45 @@ __global__ __launch_bounds__(256) void splitk_reduce_epilogue(const ConvParams p
 // OIHW -> packed [step][Cout][16] (see header comment).  cs = padded input channel count.
 // `transposed` != 0: pack the data-gradient operator instead: W'[o=ci][i=co][kh][kw] = W[co][ci][KH-1-kh][KW-1-kw]
 // (Cout/Cin below are then the TRANSPOSED operator's sizes, i.e. Cout = forward Cin).
+__device__ __forceinline__ float pack_conv_weight_value(const float* __restrict__ w, size_t i, int Cout, int Cin, int KH, int KW, int cs,
+                                                        int transposed) {
+    const int k16 = (int)(i & 15);
+    const int co = (int)((i >> 4) % Cout);
+    const int s = (int)((i >> 4) / Cout);
+    int kh, kw, c;
+    if (cs >= 16) {
+        const int cb_per_tap = cs / 16;
+        const int tap = s / cb_per_tap, cb = s - tap * cb_per_tap;
+        kh = tap / KW; kw = tap - kh * KW; c = cb * 16 + k16;
+    } else if (cs == 4) {
+        kh = s / (KW / 4); kw = (s - kh * (KW / 4)) * 4 + (k16 >> 2); c = k16 & 3;
+    } else {  // cs == 8
+        kh = s / (KW / 2); kw = (s - kh * (KW / 2)) * 2 + (k16 >> 3); c = k16 & 7;
+    }
+    if (c >= Cin) return 0.f;
+    if (!transposed) return w[(((size_t)co * Cin + c) * KH + kh) * KW + kw];
+    return w[(((size_t)c * Cout + co) * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)];   // forward layout [Cin'][Cout'] = [c][co]
+}
+
 __global__ void pack_conv_weight_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cout, int Cin,
                                         int KH, int KW, int cs, int nsteps, int transposed) {
     const size_t total = (size_t)nsteps * Cout * 16;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-        const int k16 = (int)(i & 15);
-        const int co = (int)((i >> 4) % Cout);
-        const int s = (int)((i >> 4) / Cout);
-        int kh, kw, c;
-        if (cs >= 16) {
-            const int cb_per_tap = cs / 16;
-            const int tap = s / cb_per_tap, cb = s - tap * cb_per_tap;
-            kh = tap / KW; kw = tap - kh * KW; c = cb * 16 + k16;
-        } else if (cs == 4) {
-            kh = s / (KW / 4); kw = (s - kh * (KW / 4)) * 4 + (k16 >> 2); c = k16 & 3;
-        } else {  // cs == 8
-            kh = s / (KW / 2); kw = (s - kh * (KW / 2)) * 2 + (k16 >> 3); c = k16 & 7;
-        }
-        float v = 0.f;
-        if (c < Cin) {
-            if (!transposed) v = w[(((size_t)co * Cin + c) * KH + kh) * KW + kw];
-            else v = w[(((size_t)c * Cout + co) * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)];   // forward layout [Cin'][Cout'] = [c][co]
-        }
-        wp[i] = v;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+        wp[i] = pack_conv_weight_value(w, i, Cout, Cin, KH, KW, cs, transposed);
+}
+
+// Many weights in one launch (training: every conv weight changes every optimizer step and is needed twice, as the forward
+// operator and as the data-gradient operator).  desc[k].block_begin is the exclusive prefix of 256-element blocks.
+__global__ void pack_conv_weights_batched_kernel(const sbgm_pack_desc* __restrict__ desc, int n) {
+    int lo = 0, hi = n - 1;                                  // last descriptor whose first block is <= blockIdx.x
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (desc[mid].block_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
     }
+    const sbgm_pack_desc d = desc[lo];
+    const size_t total = (size_t)d.nsteps * d.Cout * 16;
+    const size_t i = (size_t)(blockIdx.x - d.block_begin) * 256 + threadIdx.x;
+    if (i < total) d.dst[i] = pack_conv_weight_value(d.src, i, d.Cout, d.Cin, d.KH, d.KW, d.cs, d.transposed);
 }
 
 template <int KH, int KW, int S, int PAD, int CMODE>
@@ -333,6 +349,13 @@ int sbgm_launch_pack_conv_weight(const float* w_oihw, float* wp, int Cout, int C
     const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
     hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(blocks), dim3(256), 0, st, w_oihw, wp, Cout, Cin, KH, KW, cs, nsteps,
                        transposed);
+    SBGM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sbgm_launch_pack_conv_weights_batched(const sbgm_pack_desc* desc_dev, int n, int total_blocks, hipStream_t st) {
+    SBGM_CHECK(desc_dev && n >= 1 && total_blocks >= 1, "pack_weights_batched: bad arguments");
+    hipLaunchKernelGGL(pack_conv_weights_batched_kernel, dim3(total_blocks), dim3(256), 0, st, desc_dev, n);
     SBGM_LAUNCH_CHECK();
     return 0;
 }

@@ -42,7 +42,12 @@ int sbgm_conv_nsteps(int KH, int KW, int cs);
 // transposed != 0 packs the data-gradient operator (swap Cout/Cin, flip taps); then Cout/Cin are the transposed sizes
 int sbgm_launch_pack_conv_weight(const float* w_oihw, float* wp, int Cout, int Cin, int KH, int KW, int cs, hipStream_t st,
                                  int transposed = 0);
+struct sbgm_pack_desc;
+int sbgm_launch_pack_conv_weights_batched(const sbgm_pack_desc* desc_dev, int n, int total_blocks, hipStream_t st);
 int sbgm_launch_conv(const ConvGeom& g, ConvParams p, const ConvTile& cfg, float* partial_ws, hipStream_t st);
+// When set, the launchers below trust that their atomically accumulated scratch (weight-gradient slab, norm-backward sums)
+// arrives zeroed and skip their own memsets (the training path zeroes one pooled buffer per step instead of ~75 small ones).
+extern int sbgm_scratch_prezeroed;
 
 // ---- conv_wino.hip: 3x3 stride-1 pad-1 convolution, 1-D Winograd F(2,3) along rows ------------------------------------
 size_t sbgm_wino_packed_floats(int Cout, int cs);

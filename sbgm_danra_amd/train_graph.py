@@ -43,6 +43,103 @@ def _splitk_ws(dev):
     return ws
 
 
+# ---- per-step pools --------------------------------------------------------------------------------------------------------
+# Backward scratch that is accumulated with atomics (weight-gradient slabs, norm-backward sums) comes out of ONE buffer that
+# forward_train zeroes once per step; slices are handed out sequentially and never reused before the next forward, so every
+# slice is still zero when its kernel runs (a second backward through the same graph simply takes fresh slices).
+_ZERO_FLOATS = 32 << 20
+_ZERO = {}             # device -> [buffer, offset]
+
+
+def _zero_reset(dev):
+    z = _ZERO.get(dev)
+    if z is None:
+        z = _ZERO[dev] = [torch.empty(_ZERO_FLOATS, device=dev), 0]
+    z[0].zero_()
+    z[1] = 0
+
+
+def _zeros(n, dev):
+    """n zeroed floats: a slice of the step's pool (second value True -> the launcher may skip its own memset) or a fresh tensor"""
+    z = _ZERO.get(dev)
+    n_al = (n + 63) // 64 * 64
+    if z is None or z[1] + n_al > _ZERO_FLOATS:
+        return torch.zeros(n, device=dev), False
+    out = z[0][z[1]: z[1] + n]
+    z[1] += n_al
+    return out, True
+
+
+class _prezeroed:
+    """`with _prezeroed(flag):` tells the backward launchers that their scratch arrives zeroed (skips ~75 memsets per step)"""
+    def __init__(self, on):
+        self.on = on
+
+    def __enter__(self):
+        self.prev = _L().sbgm_set_scratch_prezeroed(1) if self.on else None
+
+    def __exit__(self, *exc):
+        if self.on:
+            _L().sbgm_set_scratch_prezeroed(self.prev)
+
+
+# Conv / linear weights change every optimizer step and are needed twice per step (forward operator and data-gradient
+# operator).  The first forward records which weights are used and how; from then on ONE batched launch at the start of
+# forward_train packs all of them (sbgm_conv_pack_weights_batched) instead of ~90 single-weight launches.
+class _PackPlan:
+    def __init__(self):
+        self.entries = {}          # (data_ptr, cs) -> dict(w_shape, cs, dgrad, fwd=tensor, bwd=tensor|None)
+        self.desc = None           # device descriptor table
+        self.sig = None
+        self.blocks = 0
+        self.fresh = False
+
+    def note(self, w, cs, dgrad):
+        key = (w.data_ptr(), cs)
+        e = self.entries.get(key)
+        if e is None:
+            self.entries[key] = dict(shape=tuple(w.shape), cs=cs, dgrad=dgrad, fwd=None, bwd=None)
+            self.desc = None
+        elif dgrad and not e["dgrad"]:
+            e["dgrad"] = True
+            self.desc = None
+
+    def lookup(self, w, cs):
+        e = self.entries.get((w.data_ptr(), cs)) if self.fresh else None
+        return e if e is not None and e["fwd"] is not None and e["shape"] == tuple(w.shape) else None
+
+    def build(self, dev):
+        descs, blk = [], 0
+        for (ptr, cs), e in self.entries.items():
+            cout, cin, k, _ = e["shape"]
+            e["fwd"] = torch.empty(_L().sbgm_conv_packed_numel(cout, k, k, cs), device=dev)
+            jobs = [(e["fwd"], cout, cin, cs, 0)]
+            if e["dgrad"]:
+                e["bwd"] = torch.empty(_L().sbgm_conv_packed_numel(cin, k, k, cout), device=dev)
+                jobs.append((e["bwd"], cin, cout, (cout + 15) // 16 * 16, 1))
+            for dst, co_, ci_, cs_, tr in jobs:
+                nsteps = dst.numel() // (co_ * 16)
+                descs.append(N.PackDesc(ptr, dst.data_ptr(), co_, ci_, k, k, cs_, nsteps, tr, blk))
+                blk += (dst.numel() + 255) // 256
+        raw = (N.PackDesc * len(descs))(*descs)
+        host = torch.frombuffer(bytearray(bytes(raw)), dtype=torch.uint8)
+        self.desc, self.n, self.blocks = host.to(dev), len(descs), blk
+
+    def run(self, dev):
+        """pack everything recorded so far (no-op until the first forward has recorded the weights)"""
+        self.fresh = False
+        if not self.entries or torch.cuda.is_current_stream_capturing() and self.desc is None:
+            return
+        if self.desc is None:
+            self.build(dev)
+        N.check(_L().sbgm_conv_pack_weights_batched(self.desc.data_ptr(), self.n, self.blocks, _st()))
+        self.fresh = True
+
+
+_PLANS = {}            # id(net) -> _PackPlan
+_ACTIVE_PLAN = [None]
+
+
 def _conv_launch(x, packed, out, cs, cout, k, stride, pad, bias=None, res=None, tbias=None, in_dil=0, out_hw=(0, 0)):
     """One convolution through the per-op C ABI.  The first time a geometry is seen (outside graph capture) the library
     times its kernel / tile / split-K candidates on these very operands and the winner is reused from then on."""
@@ -69,13 +166,23 @@ class ConvFn(torch.autograd.Function):
     def forward(ctx, x, w, bias, res, tbias, stride, pad):
         B, H, W, cs = x.shape
         cout, cin, k, _ = w.shape
-        packed = torch.empty(_L().sbgm_conv_packed_numel(cout, k, k, cs), device=x.device)
-        N.check(_L().sbgm_conv_pack_weight(w.data_ptr(), packed.data_ptr(), cout, cin, k, k, cs, _st()))
+        plan = _ACTIVE_PLAN[0]
+        e = plan.lookup(w, cs) if plan is not None else None
+        if e is not None:
+            packed = e["fwd"]
+        else:
+            packed = torch.empty(_L().sbgm_conv_packed_numel(cout, k, k, cs), device=x.device)
+            N.check(_L().sbgm_conv_pack_weight(w.data_ptr(), packed.data_ptr(), cout, cin, k, k, cs, _st()))
+            base = w._base if w._base is not None else w
+            if plan is not None and base.is_leaf and base.data_ptr() == w.data_ptr() and base.numel() == w.numel():
+                # a parameter or a reshaped view of one (nn.Linear weights), not a derived tensor: batch-pack it from the next step on
+                plan.note(w, cs, dgrad=x.requires_grad and cs == cin and cs % 32 == 0)
         oh, ow = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
         y = torch.empty(B, oh, ow, cout, device=x.device)
         _conv_launch(x, packed, y, cs, cout, k, stride, pad, bias, res, tbias)
         ctx.save_for_backward(x, w)
         ctx.geom = (stride, pad, bias is not None, res is not None, tbias is not None)
+        ctx.packed_bwd = e["bwd"] if e is not None else None
         return y
 
     @staticmethod
@@ -89,15 +196,18 @@ class ConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if cs != cin or cs % 32:
                 raise NotImplementedError("data gradient w.r.t. a channel-padded input is not needed on this path")
-            packed = torch.empty(_L().sbgm_conv_packed_numel(cin, k, k, cout), device=x.device)
-            N.check(_L().sbgm_conv_pack_weight_dgrad(w.data_ptr(), packed.data_ptr(), cout, cin, k, k, _st()))
+            packed = ctx.packed_bwd
+            if packed is None:
+                packed = torch.empty(_L().sbgm_conv_packed_numel(cin, k, k, cout), device=x.device)
+                N.check(_L().sbgm_conv_pack_weight_dgrad(w.data_ptr(), packed.data_ptr(), cout, cin, k, k, _st()))
             dx = torch.empty_like(x)
             _conv_launch(dy, packed, dx, cout, cin, k, 1, k - 1 - pad, in_dil=2 if stride == 2 else 0, out_hw=(H, W))
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
-            ws = torch.empty(k * k * cout * cs, device=x.device)
-            N.check(_L().sbgm_conv2d_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), ws.data_ptr(), B, H, W, cs, cin, cout, k, k,
-                                           stride, pad, _st()))
+            ws, pooled = _zeros(k * k * cout * cs, x.device)
+            with _prezeroed(pooled):
+                N.check(_L().sbgm_conv2d_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), ws.data_ptr(), B, H, W, cs, cin, cout, k, k,
+                                               stride, pad, _st()))
         if has_bias and ctx.needs_input_grad[2]:
             db = torch.empty(cout, device=x.device)
             N.check(_L().sbgm_colsum(dy.data_ptr(), None, db.data_ptr(), dy.numel() // cout, cout, _st()))
@@ -139,10 +249,11 @@ class BNTrainFn(torch.autograd.Function):
         B, H, W, Cc = x.shape
         dx, dres = torch.empty_like(x), (torch.empty_like(x) if has_res else None)
         dg, db = torch.empty(Cc, device=x.device), torch.empty(Cc, device=x.device)
-        s12 = torch.empty(B * Cc * 2, device=x.device)
+        s12, pooled = _zeros(B * Cc * 2, x.device)
         mr = ws.data_ptr() + 16 * Cc                     # [C][2] floats behind the 2C doubles
-        N.check(_L().sbgm_batchnorm_bwd(x.data_ptr(), dy.data_ptr(), y.data_ptr(), gamma.data_ptr(), N.ptr(tb_after), mr, int(relu),
-                                        dx.data_ptr(), N.ptr(dres), dg.data_ptr(), db.data_ptr(), s12.data_ptr(), B, H * W, Cc, _st()))
+        with _prezeroed(pooled):
+            N.check(_L().sbgm_batchnorm_bwd(x.data_ptr(), dy.data_ptr(), y.data_ptr(), gamma.data_ptr(), N.ptr(tb_after), mr, int(relu),
+                                            dx.data_ptr(), N.ptr(dres), dg.data_ptr(), db.data_ptr(), s12.data_ptr(), B, H * W, Cc, _st()))
         dtb = None
         if has_tb:
             dtb = torch.empty(B, Cc, device=x.device)
@@ -177,10 +288,11 @@ class GroupNormFn(torch.autograd.Function):
         dg = torch.empty(Cc, device=dev) if gamma is not None else None
         db = torch.empty(Cc, device=dev) if gamma is not None else None
         dtb = torch.empty(B, Cc, device=dev) if tbias is not None else None
-        s12 = torch.empty(B * Cc * 2, device=dev)
-        N.check(_L().sbgm_groupnorm_bwd(x.data_ptr(), dy.data_ptr(), N.ptr(gamma), N.ptr(beta), N.ptr(skip), N.ptr(tbias), mr.data_ptr(),
-                                        act, dx.data_ptr(), N.ptr(dskip), N.ptr(dg), N.ptr(db), N.ptr(dtb), s12.data_ptr(), B, H * W, Cc,
-                                        G, _st()))
+        s12, pooled = _zeros(B * Cc * 2, dev)
+        with _prezeroed(pooled):
+            N.check(_L().sbgm_groupnorm_bwd(x.data_ptr(), dy.data_ptr(), N.ptr(gamma), N.ptr(beta), N.ptr(skip), N.ptr(tbias), mr.data_ptr(),
+                                            act, dx.data_ptr(), N.ptr(dskip), N.ptr(dg), N.ptr(db), N.ptr(dtb), s12.data_ptr(), B, H * W, Cc,
+                                            G, _st()))
         return dx, dg, db, dskip, dtb, None, None, None
 
 
@@ -358,10 +470,12 @@ def _pack_inputs(x, lsm, topo, cond, cs):
     return out
 
 
+_NBT = []
+
+
 def _bn(x, bn, res=None, tb_after=None, relu=True):
     y = BNTrainFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, res, tb_after, relu, bn.eps, bn.momentum)
-    with torch.no_grad():
-        bn.num_batches_tracked += 1
+    _NBT.append(bn.num_batches_tracked)                  # incremented together at the end of forward_train (one launch, not 20)
     return y
 
 
@@ -378,6 +492,18 @@ def _attention(mod, x):                               # x: [B, H, W, C] -> same 
 
 
 def forward_train(net, x, t, y, cond, lsm, topo):
+    plan = _PLANS.setdefault(id(net), _PackPlan())
+    _ACTIVE_PLAN[0] = plan
+    _NBT.clear()
+    _zero_reset(x.device)
+    plan.run(x.device)
+    try:
+        return _forward_train(net, x, t, y, cond, lsm, topo)
+    finally:
+        _ACTIVE_PLAN[0] = None
+
+
+def _forward_train(net, x, t, y, cond, lsm, topo):
     enc, dec = net.encoder, net.decoder
     sigma = float(net.sigma)
 
@@ -426,4 +552,7 @@ def forward_train(net, x, t, y, cond, lsm, topo):
             cur = _attention(blk.attention, cur)
     fin = dec.final_layer
     a = upsampled(fin, cur)
+    if _NBT:
+        with torch.no_grad():
+            torch._foreach_add_(list(_NBT), 1)
     return Cout1Fn.apply(a, fin.conv.weight, fin.conv.bias, t, sigma)
