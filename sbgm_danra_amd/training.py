@@ -107,6 +107,48 @@ class TrainingPipeline_general:
         return x, self.loss_fn(self.model, x, self.marginal_prob_std_fn, y=seasons, cond_img=cond, lsm_cond=lsm,
                                topo_cond=topo, sdf_cond=sdf if self.sdf_weighted_loss else None)
 
+    def _graph_step(self, samples):
+        """`training.use_hip_graph: true` — loss_fn + backward of one step replayed as a hipGraph (torch.cuda.graphs over the
+        C-ABI launches): the ~700 launches of a step cost one host call.  The batch is copied into static input tensors; the
+        first batch of a new shape runs 2 eager warm-up steps' worth of launches (tile tuning, weight-pack plan) and captures.
+        Gradients land in the parameters' (static) .grad tensors exactly as after loss.backward()."""
+        x, seasons, cond, _lsm_hr, lsm, sdf, topo, _hp, _lp = self._extract(samples, "train")
+        live = [x, seasons, cond, lsm, topo, sdf if self.sdf_weighted_loss else None]
+        key = tuple(None if t is None else (tuple(t.shape), t.dtype) for t in live)
+        g = getattr(self, "_graphs", None)
+        if g is None:
+            g = self._graphs = {}
+        ent = g.get(key)
+        if ent is None:
+            static = [None if t is None else t.clone() for t in live]
+
+            def fwd_bwd():
+                loss = self.loss_fn(self.model, static[0], self.marginal_prob_std_fn, y=static[1], cond_img=static[2],
+                                    lsm_cond=static[3], topo_cond=static[4], sdf_cond=static[5])
+                loss.backward()
+                return loss
+            saved = {k: v.detach().clone() for k, v in self.model.state_dict().items()}      # warm-up must not train
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    self.optimizer.zero_grad(set_to_none=True)
+                    fwd_bwd()
+            torch.cuda.current_stream().wait_stream(side)
+            self.model.load_state_dict(saved)                                                  # BatchNorm running statistics back
+            graph = torch.cuda.CUDAGraph()
+            self.optimizer.zero_grad(set_to_none=True)
+            with torch.cuda.graph(graph):
+                loss = fwd_bwd()
+            ent = g[key] = (graph, static, loss)
+            # the capture itself did not execute: the replay below is this batch's step
+        graph, static, loss = ent
+        for s_, t in zip(static, live):
+            if s_ is not None:
+                s_.copy_(t)
+        graph.replay()
+        return x, loss
+
     def train_batches(self, dataloader, epochs=10, current_epoch=1, verbose=True, use_mixed_precision=False):
         if use_mixed_precision:
             raise NotImplementedError("fp32 only: the reference's autocast branch is commented out (training.py:325-343)")
@@ -114,12 +156,16 @@ class TrainingPipeline_general:
         if self._bucket is None and parallel.world()[1] > 1:
             self._bucket = parallel.GradientBucket(self.model.parameters())
         loss_sum = 0.0
+        use_graph = bool(self.cfg["training"].get("use_hip_graph", False)) and torch.device(self.device).type == "cuda"
         for idx, samples in enumerate(dataloader):
-            self.optimizer.zero_grad()
-            x, batch_loss = self._loss(samples)
+            if use_graph:
+                x, batch_loss = self._graph_step(samples)
+            else:
+                self.optimizer.zero_grad()
+                x, batch_loss = self._loss(samples)
+                batch_loss.backward()
             if self.extreme_enabled and idx % self.extreme_every_step == 0:
                 self._check_ground_truth(x)
-            batch_loss.backward()
             if self._bucket is not None:
                 self._bucket.all_reduce_()            # the one collective of the path
             self.optimizer.step()

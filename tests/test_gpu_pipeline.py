@@ -176,3 +176,29 @@ def test_training_with_device_side_condition_dropout(cfg_path):
     assert torch.isfinite(got) and abs(float(got) - float(want)) <= 1e-5 * abs(float(want))
     model.train()
     assert np.isfinite(pipe.train_batches(synthetic_loader(cfg, 2, n_items=4, raw_geo=True), epochs=1, verbose=False))
+
+
+def test_training_step_as_hip_graph(cfg_path):
+    """training.use_hip_graph: forward + backward replayed as one graph; parameters move, the loss stays finite, BatchNorm
+    counters advance by exactly one per step (the capture warm-up is rolled back), and a second epoch reuses the graph."""
+    from sbgm.score_unet import diffusion_coeff_fn, loss_fn, marginal_prob_std_fn
+    from sbgm.training import TrainingPipeline_general
+    from sbgm.training_utils import get_model, get_optimizer
+    from sbgm.utils import load_config
+    from sbgm_danra_amd.synthetic_data import synthetic_loader
+    cfg = load_config(cfg_path)
+    cfg.training.use_hip_graph = True
+    cfg.monitoring.extreme_prcp.enabled = False
+    torch.manual_seed(0)
+    model, _, _ = get_model(cfg)
+    pipe = TrainingPipeline_general(model, loss_fn, marginal_prob_std_fn, diffusion_coeff_fn, get_optimizer(cfg, model),
+                                    torch.device("cuda"), None, cfg)
+    before = model.encoder.conv2.weight.detach().clone()
+    dl = synthetic_loader(cfg, 2, n_items=6)
+    a = pipe.train_batches(dl, epochs=2, current_epoch=1, verbose=False)
+    assert np.isfinite(a) and int(model.encoder.bn1.num_batches_tracked) == 3
+    assert not torch.equal(before, model.encoder.conv2.weight)
+    b = pipe.train_batches(dl, epochs=2, current_epoch=2, verbose=False)
+    assert np.isfinite(b) and int(model.encoder.bn1.num_batches_tracked) == 6 and len(pipe._graphs) == 1
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for k, p in model.named_parameters()
+               if not k.startswith("decoder.final_layer.time_"))
