@@ -165,7 +165,7 @@ typedef struct sbgm_conv_args {
     int tbias_after_act;
     int tile_co, tile_px;    /* wave tile in 16-element fragments: {2,4} x {1,2,4}; 0 = default */
     int splits;              /* split-K over the grid (needs ws); 0/1 = off */
-    int waves_per_tile;      /* in-workgroup split-K: 1, 2 or 4 waves share one tile; 0 = 1 */
+    int waves_per_tile;      /* in-workgroup split-K: 1, 2 or 4 waves share one tile (8 with winograd bit 0 alone); 0 = 1 */
     int winograd;            /* bit 0: Winograd F(2,3) weights/kernel (3x3/s1/p1; w_packed from sbgm_conv_wino_pack_weight;
                                 tile_px counts 32-pixel fragments: {4,1} {2,2} {2,1} {4,2});
                                 bit 1: LDS-staged kernel (W %% 16 == 0; tile_px = tile rows per wave, 2x that with bit 0);

@@ -25,14 +25,16 @@ struct WFrags {
     f32x4 d[FPP][4];      // [pair fragment][input column 0..3]
 };
 
+// WS = 8 runs 8 waves (512 threads) on one tile: two waves per SIMD instead of one for the small-map layers, whose tile count
+// cannot fill the chip any other way; the partials are combined in two LDS rounds (8 -> 4 -> 1) so the scratch stays <= 64 KB.
 template <int FCO, int FPP, int WS>
-__global__ __launch_bounds__(256) void conv3x3_wino_kernel(const ConvParams p) {
+__global__ __launch_bounds__(WS > 4 ? 512 : 256) void conv3x3_wino_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r16 = lane & 15, kq = lane >> 4;
     const int lb = xcd_contiguous_block(blockIdx.x, gridDim.x);
-    constexpr int TPW = 4 / WS;
+    constexpr int TPW = WS > 4 ? 1 : 4 / WS;
     const int tslot = wave / WS, kpart = wave - tslot * WS;
     const int tile_raw = lb * TPW + tslot;
     const bool tile_ok = tile_raw < p.n_px_tiles * p.n_co_tiles;
@@ -147,27 +149,36 @@ __global__ __launch_bounds__(256) void conv3x3_wino_kernel(const ConvParams p) {
     if (WS > 1) {                                       // in-workgroup split-K: combine the Winograd-domain partials
         f32x4* red = reinterpret_cast<f32x4*>(smem_raw);
         constexpr int NF = 4 * FCO * FPP;
-        if (kpart > 0) {
-            f32x4* dst = red + ((tslot * (WS - 1) + (kpart - 1)) * NF) * 64 + lane;
+        auto put = [&](int slot) {
+            f32x4* dst = red + (size_t)slot * NF * 64 + lane;
 #pragma unroll
             for (int xi = 0; xi < 4; ++xi)
 #pragma unroll
                 for (int i = 0; i < FCO; ++i)
 #pragma unroll
                     for (int j = 0; j < FPP; ++j) dst[((xi * FCO + i) * FPP + j) * 64] = acc[xi][i][j];
-        }
-        __syncthreads();
-        if (kpart > 0 || !tile_ok) return;
-#pragma unroll
-        for (int k = 0; k < WS - 1; ++k) {
-            const f32x4* src = red + ((tslot * (WS - 1) + k) * NF) * 64 + lane;
+        };
+        auto add = [&](int slot) {
+            const f32x4* src = red + (size_t)slot * NF * 64 + lane;
 #pragma unroll
             for (int xi = 0; xi < 4; ++xi)
 #pragma unroll
                 for (int i = 0; i < FCO; ++i)
 #pragma unroll
                     for (int j = 0; j < FPP; ++j) acc[xi][i][j] += src[((xi * FCO + i) * FPP + j) * 64];
+        };
+        if (WS == 8) {                                  // round 1: waves 4..7 hand over to waves 0..3
+            if (kpart >= 4) put(kpart - 4);
+            __syncthreads();
+            if (kpart < 4) add(kpart);
+            __syncthreads();                            // the slots are reused by round 2; every wave stays until the last barrier
         }
+        constexpr int W2 = WS == 8 ? 4 : WS;
+        if (kpart > 0 && kpart < W2) put(tslot * (W2 - 1) + (kpart - 1));
+        __syncthreads();
+        if (kpart > 0 || !tile_ok) return;
+#pragma unroll
+        for (int k = 0; k < W2 - 1; ++k) add(tslot * (W2 - 1) + k);
     }
 
     // ---- output transform + epilogue: lane owns channels co0+16i+4kq..+3 of the two pixels of pair q0+16j+r16 ----------
@@ -255,7 +266,7 @@ int sbgm_launch_pack_wino_weight(const float* w_oihw, float* up, int Cout, int C
 int sbgm_launch_conv_wino(ConvParams p, const ConvTile& cfg, hipStream_t st) {
     SBGM_CHECK(p.Cs % 16 == 0 && p.W % 2 == 0, "wino: needs Cin padded to 16 and an even width (Cs=%d W=%d)", p.Cs, p.W);
     SBGM_CHECK(p.Cout % (16 * cfg.fco) == 0, "wino: Cout=%d not a multiple of the %d-row tile", p.Cout, 16 * cfg.fco);
-    SBGM_CHECK(cfg.splits <= 1 && (cfg.ws == 1 || cfg.ws == 2 || cfg.ws == 4), "wino: no grid split-K; waves-per-tile 1, 2 or 4");
+    SBGM_CHECK(cfg.splits <= 1 && (cfg.ws == 1 || cfg.ws == 2 || cfg.ws == 4 || cfg.ws == 8), "wino: no grid split-K; waves-per-tile 1, 2, 4 or 8");
     SBGM_CHECK(p.act == SBGM_ACT_NONE || p.act == SBGM_ACT_RELU || p.act == SBGM_ACT_GELU, "wino: act=%d does not fuse", p.act);
     SBGM_CHECK((size_t)p.B * p.H * p.W * p.Cs * 4 < (1ull << 31), "wino: input tensor exceeds 2 GiB buffer window");
     SBGM_CHECK(p.proj_w == nullptr || (p.Cout == 16 * cfg.fco && p.proj_out != nullptr), "wino: tap projection needs one co tile");
@@ -268,17 +279,20 @@ int sbgm_launch_conv_wino(ConvParams p, const ConvTile& cfg, hipStream_t st) {
     p.n_co_tiles = p.Cout / (16 * cfg.fco);
     p.x_bytes = (uint32_t)((size_t)p.B * p.H * p.W * p.Cs * 4);
     p.w_bytes = (uint32_t)(sbgm_wino_packed_floats(p.Cout, p.Cs) * 4);
-    const int ntiles = p.n_px_tiles * p.n_co_tiles, tpw = 4 / cfg.ws;
+    const int ntiles = p.n_px_tiles * p.n_co_tiles, tpw = cfg.ws > 4 ? 1 : 4 / cfg.ws;
     dim3 grid((ntiles + tpw - 1) / tpw);
     int rc = 1;
 #define SBGM_W(FC, FP, W_)                                                                                   \
     if (cfg.fco == FC && cfg.fpx == FP && cfg.ws == W_) {                                                     \
-        const size_t lds = W_ > 1 ? (size_t)(4 / W_) * (W_ - 1) * 4 * FC * FP * 64 * 16 : 0;                   \
-        hipLaunchKernelGGL((conv3x3_wino_kernel<FC, FP, W_>), grid, dim3(256), lds, st, p);                  \
+        const size_t lds = W_ == 8 ? (size_t)4 * 4 * FC * FP * 64 * 16                                         \
+                                   : (W_ > 1 ? (size_t)(4 / W_) * (W_ - 1) * 4 * FC * FP * 64 * 16 : 0);       \
+        if (lds > 64 * 1024)                                                                                  \
+            SBGM_HIP(hipFuncSetAttribute((const void*)conv3x3_wino_kernel<FC, FP, W_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((conv3x3_wino_kernel<FC, FP, W_>), grid, dim3(W_ > 4 ? 512 : 256), lds, st, p);   \
         rc = 0;                                                                                              \
     }
 #define SBGM_WT(W_) SBGM_W(4, 1, W_) SBGM_W(2, 2, W_) SBGM_W(2, 1, W_) SBGM_W(4, 2, W_)
-    SBGM_WT(1) SBGM_WT(2) SBGM_WT(4)
+    SBGM_WT(1) SBGM_WT(2) SBGM_WT(4) SBGM_WT(8)
 #undef SBGM_WT
 #undef SBGM_W
     SBGM_CHECK(rc == 0, "wino: no kernel for tile=%dx%d ws=%d", cfg.fco, cfg.fpx, cfg.ws);

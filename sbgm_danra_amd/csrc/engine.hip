@@ -397,7 +397,7 @@ int sbgm_tune_conv(const ConvGeom& g, const ConvParams& p, float* partial, size_
         for (auto& t : wt) {
             if (p.Cout % (16 * t[0])) continue;
             if (p.proj_w && 16 * t[0] != p.Cout) continue;
-            for (int ws : {1, 2, 4}) {
+            for (int ws : {1, 2, 4, 8}) {
                 if (ws > 1 && nsw / ws < 2) continue;
                 cands.push_back(ConvTile{t[0], t[1], 1, ws, 1, 0});
             }
@@ -1036,7 +1036,7 @@ int sbgm_model_tune_load(sbgm_model* m, const char* path) {
                              &k.Cs, &k.Cout, &k.proj, &t[0], &t[1], &t[2], &t[3], &t[4], &t[5]);
         // the launchers reject tiles they do not instantiate; here only the ranges that index memory are checked
         const bool ok = n == 16 && (t[0] == 1 || t[0] == 2 || t[0] == 4) && (t[1] == 1 || t[1] == 2 || t[1] == 4) && t[2] >= 1 &&
-                        t[2] <= 64 && (t[3] == 1 || t[3] == 2 || t[3] == 4) && (t[4] | 1) == 1 && t[5] >= 0 && t[5] <= 2 &&
+                        t[2] <= 64 && (t[3] == 1 || t[3] == 2 || t[3] == 4 || t[3] == 8) && (t[4] | 1) == 1 && t[5] >= 0 && t[5] <= 2 &&
                         k.Cout % (16 * t[0]) == 0;
         if (!ok) {
             fclose(f);

@@ -149,7 +149,7 @@ def run_wino(x, w, tile, wpt, scale=None, bias=None, tbias=None, res=None, relu=
 @pytest.mark.parametrize("shape", [(2, 64, 8, 8, 64), (1, 64, 16, 32, 64), (2, 128, 4, 4, 128), (1, 512, 4, 4, 256), (3, 64, 2, 2, 64),
                                    (1, 16, 6, 10, 64)])
 @pytest.mark.parametrize("tile", [(4, 1), (2, 2), (2, 1), (4, 2)])
-@pytest.mark.parametrize("wpt", [1, 2, 4])
+@pytest.mark.parametrize("wpt", [1, 2, 4, 8])
 def test_conv_winograd_f23(shape, tile, wpt):
     B, Cin, H, W, Cout = shape
     x, w = rnd(B, Cin, H, W), rnd(Cout, Cin, 3, 3, seed=1, scale=1.0 / math.sqrt(Cin * 9))
