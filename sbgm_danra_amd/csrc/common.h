@@ -61,6 +61,12 @@ __device__ __forceinline__ float wave_max(float v) {
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, uint32_t bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), /*stride*/ 0, (int)bytes, 0x00020000);
 }
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef int i32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 buf_load2(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+    i32x2 v = __builtin_amdgcn_raw_buffer_load_b64(r, (int)byte_off, 0, 0);
+    return __builtin_bit_cast(f32x2, v);
+}
 __device__ __forceinline__ f32x4 buf_load4(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
     i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(r, (int)byte_off, 0, 0);
     return __builtin_bit_cast(f32x4, v);

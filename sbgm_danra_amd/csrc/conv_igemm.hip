@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             st_kh = tap / KW;
             st_kw = tap - st_kh * KW;
         } else {
-            constexpr int SPR = KW / (16 / (CMODE ? CMODE : 16));   // steps per filter row
+            constexpr int SPR = KW / (16 / (CMODE ? CMODE : 16)) > 0 ? KW / (16 / (CMODE ? CMODE : 16)) : 1;   // steps per filter row
             st_kh = s / SPR;
             st_kw = (s - st_kh * SPR) * (16 / (CMODE ? CMODE : 16));
             st_cb = 0;
@@ -117,6 +117,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         int kw_lane, coff;
         if (CMODE == 0) { kw_lane = st_kw; coff = st_cb * 16 + kq * 4; }
         else if (CMODE == 4) { kw_lane = st_kw + kq; coff = 0; }
+        else if (CMODE == 2) { kw_lane = st_kw + 2 * kq; coff = 0; }       // two taps x the 2 real channels of 4-slot pixels
         else { kw_lane = st_kw + (kq >> 1); coff = (kq & 1) * 4; }
         const uint32_t wo = (uint32_t)st_s * w_step_stride + w_lane_off;
 #pragma unroll
@@ -129,6 +130,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                 ok = ((iy | ix) & 1) == 0;
                 iy >>= 1;
                 ix >>= 1;
+            }
+            if (CMODE == 2) {                                   // taps ix, ix+1: the first 8 bytes of two neighbouring pixels
+                const bool oky = (unsigned)iy < (unsigned)p.H;
+                const uint32_t off = (uint32_t)((pl[f].base + iy * p.W + ix) * p.Cs) * 4u;
+                const f32x2 lo = buf_load2(xr, (oky & ((unsigned)ix < (unsigned)p.W)) ? off : 0x80000000u);
+                const f32x2 hi = buf_load2(xr, (oky & ((unsigned)(ix + 1) < (unsigned)p.W)) ? off + (uint32_t)p.Cs * 4u : 0x80000000u);
+                fr.b[f] = f32x4{lo[0], lo[1], hi[0], hi[1]};
+                continue;
             }
             ok = ok & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
             const uint32_t off = (uint32_t)((pl[f].base + iy * p.W + ix) * p.Cs + coff) * 4u;
@@ -288,6 +297,8 @@ __device__ __forceinline__ float pack_conv_weight_value(const float* __restrict_
         kh = tap / KW; kw = tap - kh * KW; c = cb * 16 + k16;
     } else if (cs == 4) {
         kh = s / (KW / 4); kw = (s - kh * (KW / 4)) * 4 + (k16 >> 2); c = k16 & 3;
+    } else if (cs == 2) {
+        kh = s / (KW / 8); kw = (s - kh * (KW / 8)) * 8 + (k16 >> 1); c = k16 & 1;
     } else {  // cs == 8
         kh = s / (KW / 2); kw = (s - kh * (KW / 2)) * 2 + (k16 >> 3); c = k16 & 7;
     }
@@ -341,7 +352,7 @@ int sbgm_conv_nsteps(int KH, int KW, int cs) {
 
 int sbgm_launch_pack_conv_weight(const float* w_oihw, float* wp, int Cout, int Cin, int KH, int KW, int cs,
                                  hipStream_t st, int transposed) {
-    SBGM_CHECK(cs == 4 || cs == 8 || (cs >= 16 && cs % 16 == 0), "pack_conv_weight: bad padded Cin %d", cs);
+    SBGM_CHECK((cs == 2 && KW % 8 == 0) || cs == 4 || cs == 8 || (cs >= 16 && cs % 16 == 0), "pack_conv_weight: bad padded Cin %d", cs);
     SBGM_CHECK(cs >= 16 || KW % (16 / cs) == 0, "pack_conv_weight: KW=%d not divisible for cs=%d", KW, cs);
     SBGM_CHECK(Cin <= cs, "pack_conv_weight: Cin %d > padded %d", Cin, cs);
     const int nsteps = sbgm_conv_nsteps(KH, KW, cs);
@@ -380,8 +391,10 @@ int sbgm_launch_conv(const ConvGeom& g, ConvParams p, const ConvTile& cfg, float
         p.OW = (p.W + 2 * g.pad - g.kw) / g.stride + 1;
     }
     p.M = p.B * p.OH * p.OW;
+    const bool two_of_four = p.c_real == 2 && p.Cs == 4;
+    SBGM_CHECK(p.c_real == 0 || two_of_four, "conv: c_real=%d is only defined for 2 real channels in 4-slot pixels", p.c_real);
     p.cb_per_tap = p.Cs >= 16 ? p.Cs / 16 : 1;
-    p.nsteps = sbgm_conv_nsteps(g.kh, g.kw, p.Cs);
+    p.nsteps = sbgm_conv_nsteps(g.kh, g.kw, two_of_four ? 2 : p.Cs);
     const int splits = std::max(1, std::min(cfg.splits, p.nsteps));
     p.steps_per_split = (p.nsteps + splits - 1) / splits;
     const int real_splits = (p.nsteps + p.steps_per_split - 1) / p.steps_per_split;
@@ -397,12 +410,12 @@ int sbgm_launch_conv(const ConvGeom& g, ConvParams p, const ConvTile& cfg, float
         SBGM_CHECK(partial_ws != nullptr, "conv: split-K needs a partial workspace");
         p.out = partial_ws;
     }
-    const int cmode = p.Cs >= 16 ? 0 : p.Cs;
+    const int cmode = two_of_four ? 2 : (p.Cs >= 16 ? 0 : p.Cs);
     int rc = 1;
 #define SBGM_GEOM(KH_, KW_, S_, PAD_, CM_)                                                        \
     if (g.kh == KH_ && g.kw == KW_ && g.stride == S_ && g.pad == PAD_ && cmode == CM_)            \
         rc = launch_geom<KH_, KW_, S_, PAD_, CM_>(p, cfg, grid, st);
-    SBGM_GEOM(8, 8, 2, 3, 0) SBGM_GEOM(8, 8, 2, 3, 4) SBGM_GEOM(8, 8, 2, 3, 8)
+    SBGM_GEOM(8, 8, 2, 3, 0) SBGM_GEOM(8, 8, 2, 3, 4) SBGM_GEOM(8, 8, 2, 3, 8) SBGM_GEOM(8, 8, 2, 3, 2)
     SBGM_GEOM(3, 3, 1, 1, 0) SBGM_GEOM(3, 3, 2, 1, 0) SBGM_GEOM(1, 1, 2, 0, 0) SBGM_GEOM(1, 1, 1, 0, 0)
     SBGM_GEOM(8, 8, 1, 4, 0)                       // data-gradient of the 8x8/s2/p3 stem convolution
 #undef SBGM_GEOM

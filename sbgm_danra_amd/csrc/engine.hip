@@ -81,7 +81,7 @@ struct sbgm_model {
     std::map<ConvOpKey, ConvTile> tuned;
     ConvTile last_tile{};                   // tile of the most recent conv() (tells the caller whether GroupNorm statistics were fused)
     bool tuning = false;
-    struct ConvRec { ConvGeom g; int B, H, W, Cs, Cout, M, nsteps; ConvTile t; double flops; hipEvent_t e0, e1; float ms; };
+    struct ConvRec { ConvGeom g; int B, H, W, Cs, Cout, M, nsteps; ConvTile t; double flops; hipEvent_t e0, e1; float ms; int c_real; };
     std::vector<ConvRec>* prof = nullptr;   // when set, conv() brackets every launch with events
     static constexpr int PROF_REPS = 4;
     hipStream_t graph_stream = nullptr;     // private capture stream (the caller's may be the legacy default stream)
@@ -178,7 +178,9 @@ int sbgm_model::build(const sbgm_model_config& c) {
     cs_in = pad_channels(cin_total);
     SBGM_CHECK(cs_in <= 16, "input channels %d > 16 unsupported", cin_total);
     // ---- encoder (registration mirrors the reference state_dict names) ------------------------------------------
-    conv1.w = convw("encoder.conv1.weight", 64, cin_total, 8, 8, cs_in);
+    // 2 input channels (x + one condition, BASELINE config 2): pixels keep 4 slots but the weights are packed 8 taps x 2 channels
+    // per K step, so no MFMA work is spent on the two padding slots
+    conv1.w = convw("encoder.conv1.weight", 64, cin_total, 8, 8, cin_total == 2 ? 2 : cs_in);
     bn1 = bn("encoder.bn1", 64);
     int cin = 64;
     for (int li = 0; li < 4; ++li) {
@@ -345,7 +347,7 @@ ConvTile sbgm_model::pick_tile(const ConvGeom& g, const ConvParams& p) {
     }
     if (p.proj_w) return ConvTile{p.Cout / 16, 2, 1, 1, 0, 0};
     const int M = p.B * OH * OW;
-    const int nsteps = sbgm_conv_nsteps(g.kh, g.kw, p.Cs);
+    const int nsteps = sbgm_conv_nsteps(g.kh, g.kw, p.c_real == 2 ? 2 : p.Cs);
     const int target = 2048;                 // ~2 waves per SIMD
     const int cand[3][2] = {{4, 4}, {4, 2}, {2, 2}};
     for (auto& c : cand) {
@@ -368,7 +370,7 @@ int sbgm_tune_conv(const ConvGeom& g, const ConvParams& p, float* partial, size_
     const int OH = p.out_h > 0 ? p.out_h : (p.H + 2 * g.pad - g.kh) / g.stride + 1;
     const int OW = p.out_w > 0 ? p.out_w : (p.W + 2 * g.pad - g.kw) / g.stride + 1;
     const size_t mc = (size_t)p.B * OH * OW * p.Cout;
-    const int nsteps = sbgm_conv_nsteps(g.kh, g.kw, p.Cs);
+    const int nsteps = sbgm_conv_nsteps(g.kh, g.kw, p.c_real == 2 ? 2 : p.Cs);
     auto launch = [&](const ConvTile& ct) -> int {
         ConvParams q = p;
         if (!ct.wino && !ct.lds) return sbgm_launch_conv(g, q, ct, partial, st);
@@ -462,7 +464,7 @@ int sbgm_model::conv(const ConvGeom& g, ConvParams p, hipStream_t st) {
     if (ct.splits > 1 && mc * ct.splits > PARTIAL_FLOATS) ct.splits = (int)std::max<size_t>(1, PARTIAL_FLOATS / mc);
     last_tile = ct;
     if (!prof) return launch_any(g, p, ct, st);
-    ConvRec r{g, p.B, p.H, p.W, p.Cs, p.Cout, p.B * OH * OW, sbgm_conv_nsteps(g.kh, g.kw, p.Cs), ct, 0.0, nullptr, nullptr, 0.f};
+    ConvRec r{g, p.B, p.H, p.W, p.Cs, p.Cout, p.B * OH * OW, sbgm_conv_nsteps(g.kh, g.kw, p.c_real == 2 ? 2 : p.Cs), ct, 0.0, nullptr, nullptr, 0.f, p.c_real};
     // algorithmic FLOPs: 2 * M * Cout * (KH*KW*Cin_real); Cs may be padded (only the stem conv), count real K there
     const int cin_real = (g.kh == 8 && p.Cs <= 16) ? cin_total : p.Cs;
     r.flops = 2.0 * r.M * p.Cout * (double)(g.kh * g.kw * cin_real);
@@ -589,6 +591,7 @@ int sbgm_model::forward(const float* x, const float* t, const int64_t* y, const 
     {
         ConvParams p{};
         p.x = x0; p.wp = conv1.w->dev; p.out = fm[0]; p.tbias = tb[0]; p.B = B; p.H = H; p.W = W; p.Cs = cs_in; p.Cout = 64;
+        p.c_real = cin_total == 2 ? 2 : 0;
         if (conv(ConvGeom{8, 8, 2, 3}, p, st)) return 1;                                        // score_unet.py:312-316
     }
     int ch = H / 4, cw_ = W / 4;
@@ -999,7 +1002,7 @@ static std::string conv_kernel_name(const sbgm_model::ConvRec& r) {
     if (r.t.lds) snprintf(b, sizeof b, "conv3x3_lds_kernel<%d; %d; %s; %s>", r.t.fco, r.t.fpx, r.t.wino ? "true" : "false", r.t.lds == 2 ? "true" : "false");
     else if (r.t.wino) snprintf(b, sizeof b, "conv3x3_wino_kernel<%d; %d; %d>", r.t.fco, r.t.fpx, r.t.ws);
     else snprintf(b, sizeof b, "conv_igemm_kernel<%d; %d; %d; %d; %d; %d; %d; %d>", r.g.kh, r.g.kw, r.g.stride, r.g.pad, r.t.fco,
-                  r.t.fpx, r.Cs >= 16 ? 0 : r.Cs, r.t.ws);
+                  r.t.fpx, r.c_real == 2 ? 2 : (r.Cs >= 16 ? 0 : r.Cs), r.t.ws);
     return b;
 }
 }  // extern "C++"

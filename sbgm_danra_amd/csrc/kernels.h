@@ -31,6 +31,8 @@ struct ConvParams {
     double* gn_stats;     // conv_lds only, or null: per-workgroup GroupNorm partial sums of the OUTPUT (sum, sum of squares per
                           // group) in the [b][chunk][G][2] layout groupnorm_apply reads -> no separate statistics pass
     int gn_groups;        // G of that GroupNorm (channels per group must divide or be a multiple of the tile's channel slice)
+    int c_real;           // 0, or 2 with Cs == 4: only 2 of the 4 stored channels are real (the 2-channel stem): a K step is then
+                          // 8 taps x 2 channels (weights packed with cs = 2) instead of 4 taps x 4 slots, halving the MFMA work
     int in_dil;           // 1, or 2: read the input through a zero-inserted grid (data-gradient of a stride-2 conv)
     int out_h, out_w;     // explicit output size (required with in_dil == 2), else 0
     // filled by sbgm_launch_conv:
