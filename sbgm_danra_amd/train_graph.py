@@ -14,6 +14,7 @@ batch statistics and updates `running_mean/var/num_batches_tracked` (momentum 0.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 
 import torch
 
@@ -93,12 +94,14 @@ class _PackPlan:
         self.sig = None
         self.blocks = 0
         self.fresh = False
+        self.owner = lambda: None
 
     def note(self, w, cs, dgrad):
         key = (w.data_ptr(), cs)
         e = self.entries.get(key)
         if e is None:
-            self.entries[key] = dict(shape=tuple(w.shape), cs=cs, dgrad=dgrad, fwd=None, bwd=None)
+            base = w._base if w._base is not None else w
+            self.entries[key] = dict(shape=tuple(w.shape), cs=cs, dgrad=dgrad, fwd=None, bwd=None, ref=weakref.ref(base))
             self.desc = None
         elif dgrad and not e["dgrad"]:
             e["dgrad"] = True
@@ -128,6 +131,12 @@ class _PackPlan:
     def run(self, dev):
         """pack everything recorded so far (no-op until the first forward has recorded the weights)"""
         self.fresh = False
+        # a recorded weight whose parameter died or moved (model deleted, .to(), load with assign) must never be read again
+        stale = [k for k, e in self.entries.items() if e["ref"]() is None or e["ref"]().data_ptr() != k[0]]
+        if stale and not torch.cuda.is_current_stream_capturing():
+            for k in stale:
+                del self.entries[k]
+            self.desc = None
         if not self.entries or torch.cuda.is_current_stream_capturing() and self.desc is None:
             return
         if self.desc is None:
@@ -492,7 +501,12 @@ def _attention(mod, x):                               # x: [B, H, W, C] -> same 
 
 
 def forward_train(net, x, t, y, cond, lsm, topo):
-    plan = _PLANS.setdefault(id(net), _PackPlan())
+    plan = _PLANS.get(id(net))
+    if plan is None or plan.owner() is not net:           # ids are recycled: a plan belongs to one live model object
+        plan = _PLANS[id(net)] = _PackPlan()
+        plan.owner = weakref.ref(net)
+        for k in [k for k, v in _PLANS.items() if v.owner() is None]:
+            del _PLANS[k]
     _ACTIVE_PLAN[0] = plan
     _NBT.clear()
     _zero_reset(x.device)
