@@ -428,7 +428,7 @@ int sbgm_tune_conv(const ConvGeom& g, const ConvParams& p, float* partial, size_
     SBGM_HIP(hipEventCreate(&e1));
     float best_ms = 1e30f;
     int rc = 0;
-    for (int round = 0; round < 2 && !rc; ++round)          // two interleaved rounds, keep each candidate's best (DVFS / noise)
+    for (int round = 0; round < 3 && !rc; ++round)          // three interleaved rounds, keep each candidate's best (DVFS / noise)
         for (auto& ct : cands) {
             if (ct.splits > 1 && mc * ct.splits > partial_floats) continue;
             constexpr int REPS = 6;
