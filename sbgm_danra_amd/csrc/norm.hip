@@ -74,6 +74,7 @@ __global__ void norm_finalize_kernel(const double* __restrict__ stats, float* __
 
 // ---- GroupNorm pass 1: partial sums per (sample, chunk, group) -> stats[b][chunk][g][2] (doubles) -------------------
 constexpr int GN_MAX_CHUNKS = 64;
+constexpr int GN_APPLY_BLOCKS = 1024;   // blocks of the apply sweep over the whole batch; measured 128..16384: 1024 is best (each block re-reduces the chunk partials)
 __global__ __launch_bounds__(NORM_THREADS) void gn_partial_kernel(const float* __restrict__ x, double* __restrict__ stats,
                                                                   int HW, int C, int G, int px_per_block) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -303,7 +304,7 @@ int sbgm_launch_groupnorm_apply(const float* x, float* y, const float* gamma, co
     SBGM_CHECK(C % 4 == 0 && C <= 1024 && C % G == 0 && chunks >= 1 && chunks <= GN_MAX_CHUNKS, "groupnorm_apply: C=%d G=%d chunks=%d", C, G,
                chunks);
     const size_t per_sample = (size_t)HW * (C / 4);
-    const int bx = (int)std::max<size_t>(1, std::min<size_t>((per_sample + 255) / 256, 2048 / std::max(1, B) + 1));
+    const int bx = (int)std::max<size_t>(1, std::min<size_t>((per_sample + 255) / 256, GN_APPLY_BLOCKS / std::max(1, B) + 1));
     hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(bx, B), dim3(256), 2 * G * sizeof(float), st, x, y, gamma, beta, skip, tbias,
                        act, HW, C, G, chunks, eps, stats, mr_out);
     SBGM_LAUNCH_CHECK();
@@ -325,7 +326,7 @@ int sbgm_launch_groupnorm(const float* x, float* y, const float* gamma, const fl
                        HW, C, G, ppb);
     SBGM_LAUNCH_CHECK();
     const size_t per_sample = (size_t)HW * (C / 4);
-    const int bx = (int)std::max<size_t>(1, std::min<size_t>((per_sample + 255) / 256, 2048 / std::max(1, B) + 1));
+    const int bx = (int)std::max<size_t>(1, std::min<size_t>((per_sample + 255) / 256, GN_APPLY_BLOCKS / std::max(1, B) + 1));
     hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(bx, B), dim3(256), 2 * G * sizeof(float), st, x, y, gamma, beta, skip, tbias,
                        act, HW, C, G, chunks, eps, stats_ws, mr_out);
     SBGM_LAUNCH_CHECK();

@@ -288,6 +288,7 @@ __global__ __launch_bounds__(256) void act_kernel(float* x, size_t n4, int act) 
     }
 }
 
+// grid cap measured 512..8192 on the sampling step: 2048 blocks is best
 inline int stream_blocks(size_t work_items) { return (int)std::min<size_t>((work_items + 255) / 256, 2048); }
 
 }  // namespace
