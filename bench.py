@@ -324,7 +324,23 @@ def main():
         for k in kernels:        # Winograd F(2,3) instantiations execute 2/3 of the algorithmic (direct-convolution) FLOPs as MFMAs
             wino = "wino_kernel" in k["kernel"] or ("lds_kernel" in k["kernel"] and k["kernel"].split(",")[2].strip() == "true")
             k["executed_flop_ratio"] = 2.0 / 3.0 if wino else 1.0
-        dom = kernels[0]
+        # The dominant kernel = the kernel FUNCTION (template) with the largest share of an evaluation; the autotuner spreads its
+        # launches over several instantiations (tile / Winograd / double-buffer arguments), listed under "instantiations" with
+        # the names `rocprofv3 --stats` prints, so the two can be compared row by row.
+        fam = {}
+        for k in kernels:
+            f = fam.setdefault(k["kernel"].split("<")[0], {"launches": 0, "us": 0.0, "gflop": 0.0, "bytes": 0.0, "exec": 0.0, "inst": []})
+            f["launches"] += k["launches"]
+            f["us"] += k["avg_us"] * k["launches"]
+            f["gflop"] += k["gflop_per_launch"] * k["launches"]
+            f["bytes"] += k["alg_bytes_per_launch"] * k["launches"]
+            f["exec"] += k["gflop_per_launch"] * k["launches"] * k["executed_flop_ratio"]
+            f["inst"].append(k)
+        dname, df = max(fam.items(), key=lambda kv: kv[1]["us"])
+        dom = {"kernel": dname + "<...>", "launches": df["launches"], "avg_us": df["us"] / df["launches"],
+               "gflop_per_launch": df["gflop"] / df["launches"], "tflops": df["gflop"] / df["us"] * 1e3,
+               "alg_bytes_per_launch": df["bytes"] / df["launches"], "executed_flop_ratio": df["exec"] / df["gflop"],
+               "instantiations": df["inst"]}
         # HBM-side traffic of that kernel: PMC counters cannot be read from inside this process; they come from the
         # separately collected rocprofv3 passes (tools/collect_profiles.sh -> profiles/r01_pmc_traffic.json), if committed
         traffic, traffic_src = None, None
@@ -332,9 +348,11 @@ def main():
             tp = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
             if os.path.exists(tp):
                 with open(tp) as f:
-                    ent = json.load(f)["kernels"].get(dom["kernel"])
-                if ent and B == 32 and HW == 128:
-                    traffic, traffic_src = ent["bytes_per_launch"], f"profiles/{tag}_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE)"
+                    tk = json.load(f)["kernels"]
+                ents = [(v["bytes_per_launch"], v["launches"]) for n, v in tk.items() if n.split("<")[0] == dname]
+                if ents and B == 32 and HW == 128:
+                    traffic = sum(b * n for b, n in ents) / sum(n for _, n in ents)
+                    traffic_src = f"profiles/{tag}_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, launch-weighted over the instantiations)"
                 break
         ach = fl_conv / (ms_conv * 1e-3) * 1e-12
         ms_eval = dt / (a.steps * evals_per_step) * 1e3
@@ -349,7 +367,7 @@ def main():
                 "executed_flop_ratio": dom["executed_flop_ratio"],
                 "mfma_pipe_frac": dom["tflops"] * dom["executed_flop_ratio"] / PEAK_FP32_TFLOPS,
                 "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
-                "alg_bytes_per_launch": dom["alg_bytes_per_launch"],
+                "alg_bytes_per_launch": dom["alg_bytes_per_launch"], "instantiations": dom["instantiations"],
                 "conv_family": {"launches": n_conv, "ms_per_eval": ms_conv, "gflop_per_eval": fl_conv * 1e-9, "achieved": ach,
                                 "frac": ach / PEAK_FP32_TFLOPS},
                 "slowest_launch": {"ms": ms_max, "tflops": fl_max / (ms_max * 1e-3) * 1e-12},
