@@ -320,7 +320,7 @@ int sbgm_conv_lds_gn_chunks(const ConvParams& p, const ConvTile& cfg) {
     return chunks <= 64 ? chunks : 0;
 }
 
-// cfg: fco in {2,4}; fpx = tile rows per wave (direct: 1,2,4 -> tile 4/8/16 rows; Winograd: rows per wave = 2*fpx);
+// cfg: fco in {1,2,4}; fpx = tile rows per wave (direct: 1,2,4 -> tile 4/8/16 rows; Winograd: rows per wave = 2*fpx);
 // cfg.wino selects the Winograd slab (p.wp must then be the Winograd pack).  W must be a multiple of 16.
 int sbgm_launch_conv_lds(ConvParams p, const ConvTile& cfg, hipStream_t st) {
     SBGM_CHECK(p.Cs % 16 == 0 && p.W % 16 == 0, "conv_lds: needs Cin padded to 16 and W %% 16 == 0 (Cs=%d W=%d)", p.Cs, p.W);
@@ -351,8 +351,8 @@ int sbgm_launch_conv_lds(ConvParams p, const ConvTile& cfg, hipStream_t st) {
         rc = 0;                                                                                              \
     }
 #define SBGM_L(FC, FP, WN) SBGM_L2(FC, FP, WN, false) SBGM_L2(FC, FP, WN, true)
-    SBGM_L(4, 1, false) SBGM_L(4, 2, false) SBGM_L(4, 4, false) SBGM_L(2, 2, false) SBGM_L(2, 4, false)
-    SBGM_L(4, 1, true) SBGM_L(4, 2, true) SBGM_L(2, 1, true) SBGM_L(2, 2, true)
+    SBGM_L(4, 1, false) SBGM_L(4, 2, false) SBGM_L(4, 4, false) SBGM_L(2, 2, false) SBGM_L(2, 4, false) SBGM_L(2, 1, false)
+    SBGM_L(4, 1, true) SBGM_L(4, 2, true) SBGM_L(2, 1, true) SBGM_L(2, 2, true) SBGM_L(1, 1, true) SBGM_L(1, 2, true)
 #undef SBGM_L
 #undef SBGM_L2
     SBGM_CHECK(rc == 0, "conv_lds: no kernel for tile fco=%d fpx=%d wino=%d", cfg.fco, cfg.fpx, cfg.wino);

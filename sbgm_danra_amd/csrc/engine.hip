@@ -406,7 +406,7 @@ int sbgm_tune_conv(const ConvGeom& g, const ConvParams& p, float* partial, size_
         }
     }
     if (s1 && p.W % 16 == 0 && p.Cs % 16 == 0 && getenv("SBGM_NO_LDS_CONV") == nullptr) {
-        const int dt[5][2] = {{4, 1}, {4, 2}, {4, 4}, {2, 2}, {2, 4}};
+        const int dt[6][2] = {{4, 1}, {4, 2}, {4, 4}, {2, 2}, {2, 4}, {2, 1}};
         auto lds_bytes = [](int fco, int rows_per_wave, bool wino) {
             return ((size_t)(wino ? 12 : 9) * 16 * fco * 4 + (size_t)(4 * rows_per_wave + 2) * (wino ? 19 : 18) * 4) * 16;
         };
@@ -415,7 +415,7 @@ int sbgm_tune_conv(const ConvGeom& g, const ConvParams& p, float* partial, size_
             cands.push_back(ConvTile{t[0], t[1], 1, 1, 0, 1});
             if (2 * lds_bytes(t[0], t[1], false) <= 160 * 1024) cands.push_back(ConvTile{t[0], t[1], 1, 1, 0, 2});   // double-buffered
         }
-        const int wt2[4][2] = {{4, 1}, {4, 2}, {2, 1}, {2, 2}};
+        const int wt2[6][2] = {{4, 1}, {4, 2}, {2, 1}, {2, 2}, {1, 1}, {1, 2}};   // 16-channel slices double the workgroup count of small layers
         if (p.wp_wino)
             for (auto& t : wt2) {
                 if (p.Cout % (16 * t[0]) || (p.proj_w && 16 * t[0] != p.Cout)) continue;

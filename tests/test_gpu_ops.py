@@ -160,7 +160,8 @@ def test_conv_winograd_f23(shape, tile, wpt):
 @pytest.mark.parametrize("shape", [(2, 64, 8, 16, 64), (1, 64, 16, 32, 128), (2, 128, 12, 16, 64), (1, 16, 20, 48, 64), (1, 256, 4, 16, 64)])
 @pytest.mark.parametrize("mode,tile", [(2, (4, 1)), (2, (4, 2)), (2, (4, 4)), (2, (2, 2)), (2, (2, 4)), (3, (4, 1)), (3, (4, 2)), (3, (2, 1)),
                                        (3, (2, 2)),
-                                       (6, (4, 1)), (6, (2, 4)), (7, (2, 1)), (7, (2, 2)), (7, (4, 1))])     # +4: double-buffered stages
+                                       (6, (4, 1)), (6, (2, 4)), (7, (2, 1)), (7, (2, 2)), (7, (4, 1)),      # +4: double-buffered stages
+                                       (2, (2, 1)), (3, (1, 1)), (3, (1, 2)), (7, (1, 1))])
 def test_conv_lds_staged(shape, mode, tile):
     B, Cin, H, W, Cout = shape
     x, w = rnd(B, Cin, H, W), rnd(Cout, Cin, 3, 3, seed=1, scale=1.0 / math.sqrt(Cin * 9))
