@@ -190,7 +190,21 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const float* __res
         }
         if (tbias) bt += *reinterpret_cast<const f32x4*>(tbias + (size_t)b * C + c);
         const size_t stride = (size_t)gridDim.x * blockDim.x;        // a multiple of cq, so the quad never changes
-        for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_sample; i += stride) {
+        size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        for (; i + stride < per_sample; i += 2 * stride) {          // two independent quads in flight per thread
+            f32x4 v0 = xb[i], v1 = xb[i + stride];
+            f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = s0;
+            if (sb) { s0 = sb[i]; s1 = sb[i + stride]; }
+            v0 = (v0 - mu) * a + s0 + bt;
+            v1 = (v1 - mu) * a + s1 + bt;
+            if (act != SBGM_ACT_NONE) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { v0[e] = sbgm_act(v0[e], act); v1[e] = sbgm_act(v1[e], act); }
+            }
+            yb[i] = v0;
+            yb[i + stride] = v1;
+        }
+        if (i < per_sample) {
             f32x4 v = (xb[i] - mu) * a;
             if (sb) v += sb[i];
             v += bt;
