@@ -240,6 +240,9 @@ int sbgm_conv_pack_weight_dgrad(const float* w_oihw, float* packed, int Cout, in
 /* dW (OIHW) = sum_p dy[p,:] (x) x[p@tap,:]; ws: >= KH*KW*Cout*c_pad floats */
 int sbgm_conv2d_wgrad(const float* dy, const float* x, float* dw_oihw, float* ws, int B, int H, int W, int c_pad, int Cin,
                       int Cout, int KH, int KW, int stride, int pad, void* stream);
+/* the same, plus the bias gradient db[Cout] = sum_p dy[p,:] produced by the waves that stream dy anyway */
+int sbgm_conv2d_wgrad_bias(const float* dy, const float* x, float* dw_oihw, float* dbias, float* ws, int B, int H, int W, int c_pad,
+                           int Cin, int Cout, int KH, int KW, int stride, int pad, void* stream);
 int sbgm_colsum(const float* x, const float* y /* NULL or multiplied elementwise */, float* out, int M, int C, void* stream);
 int sbgm_samplesum(const float* x, float* out /* [B,C] */, int B, int HW, int C, void* stream);
 /* ws: >= 8*B*C bytes */

@@ -110,6 +110,7 @@ SIGNATURES = {
     "sbgm_act_inplace": (_i, [_vp, _i64, _i, _vp]),
     "sbgm_conv_pack_weight_dgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "sbgm_conv2d_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
+    "sbgm_conv2d_wgrad_bias": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "sbgm_colsum": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "sbgm_samplesum": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "sbgm_groupnorm_bwd": (_i, [_vp] * 14 + [_i, _i, _i, _i, _vp]),

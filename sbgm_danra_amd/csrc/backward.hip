@@ -22,7 +22,8 @@ inline int stream_blocks(size_t n, int cap = 2048) { return (int)std::min<size_t
 template <int FCI>   // 16*FCI input channels per wave
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                          float* __restrict__ dwp, int B, int H, int W, int Cs, int OH,
-                                                         int OW, int Cout, int KH, int KW, int S, int PAD, int px_per_split) {
+                                                         int OW, int Cout, int KH, int KW, int S, int PAD, int px_per_split,
+                                                         float* __restrict__ dbias) {
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r16 = lane & 15, kq = lane >> 4;
@@ -67,7 +68,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
             }
         }
     };
+    // bias gradient db[co] = sum_p dy[p][co] as a by-product: the waves of tap 0 / input-channel tile 0 already stream every dy
+    // row of their output-channel slice once (removes a separate column-sum launch and its memset per convolution)
+    const bool do_bias = dbias != nullptr && tap == 0 && ci_t == 0;
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     auto mma = [&](const f32x4& a, const float (&bv)[FCI]) {
+        if (do_bias) bsum += a;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -82,6 +88,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
         mma(a0, b0);
         load(p0 + 8, a0, b0);
         mma(a1, b1);
+    }
+    if (do_bias) {                                   // lanes kq = 0..3 hold the same channels 4*r16..+3 for different pixels
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            bsum[e] += __shfl_xor(bsum[e], 16, 64);
+            bsum[e] += __shfl_xor(bsum[e], 32, 64);
+        }
+        if (kq == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomicAdd(dbias + co0 + 4 * r16 + e, bsum[e]);
+        }
     }
     // D_i[row][col]: row = 4*kq + reg -> channel co0 + 4*row + i ; col = r16 -> ci0 + 16j + r16
     float* base = dwp + ((size_t)tap * Cout) * Cs;
@@ -554,7 +571,7 @@ __global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ 
 
 // ---- launchers -----------------------------------------------------------------------------------------------------
 int sbgm_launch_conv_wgrad(const float* dy, const float* x, float* dw_oihw, float* dwp_ws, int B, int H, int W, int Cs, int Cin,
-                           int Cout, int KH, int KW, int S, int PAD, hipStream_t st) {
+                           int Cout, int KH, int KW, int S, int PAD, hipStream_t st, float* dbias) {
     SBGM_CHECK(Cout % 64 == 0, "wgrad: Cout=%d must be a multiple of 64", Cout);
     SBGM_CHECK((Cs == 4 || Cs == 8 || Cs % 16 == 0) && Cin <= Cs, "wgrad: padded Cin %d unsupported (Cin=%d)", Cs, Cin);
     const int OH = (H + 2 * PAD - KH) / S + 1, OW = (W + 2 * PAD - KW) / S + 1, M = B * OH * OW;
@@ -564,9 +581,12 @@ int sbgm_launch_conv_wgrad(const float* dy, const float* x, float* dw_oihw, floa
     int pps = ((M + splits - 1) / splits + 3) / 4 * 4;
     splits = (M + pps - 1) / pps;
     const size_t n = (size_t)KH * KW * Cout * Cs;
-    if (!sbgm_scratch_prezeroed) SBGM_HIP(hipMemsetAsync(dwp_ws, 0, n * 4, st));
+    if (!sbgm_scratch_prezeroed) {
+        SBGM_HIP(hipMemsetAsync(dwp_ws, 0, n * 4, st));
+        if (dbias) SBGM_HIP(hipMemsetAsync(dbias, 0, (size_t)Cout * 4, st));
+    }
     dim3 grid((tiles + 3) / 4, splits);
-#define SBGM_WG(F) hipLaunchKernelGGL(conv_wgrad_kernel<F>, grid, dim3(256), 0, st, dy, x, dwp_ws, B, H, W, Cs, OH, OW, Cout, KH, KW, S, PAD, pps)
+#define SBGM_WG(F) hipLaunchKernelGGL(conv_wgrad_kernel<F>, grid, dim3(256), 0, st, dy, x, dwp_ws, B, H, W, Cs, OH, OW, Cout, KH, KW, S, PAD, pps, dbias)
     if (fci == 4) SBGM_WG(4); else if (fci == 2) SBGM_WG(2); else SBGM_WG(1);
 #undef SBGM_WG
     SBGM_LAUNCH_CHECK();

@@ -167,6 +167,11 @@ int sbgm_conv2d_wgrad(const float* dy, const float* x, float* dw_oihw, float* ws
                       int KH, int KW, int stride, int pad, void* stream) {
     return sbgm_launch_conv_wgrad(dy, x, dw_oihw, ws, B, H, W, c_pad, Cin, Cout, KH, KW, stride, pad, ST);
 }
+int sbgm_conv2d_wgrad_bias(const float* dy, const float* x, float* dw_oihw, float* dbias, float* ws, int B, int H, int W, int c_pad, int Cin,
+                           int Cout, int KH, int KW, int stride, int pad, void* stream) {
+    SBGM_CHECK(dbias != nullptr, "conv2d_wgrad_bias: dbias is required");
+    return sbgm_launch_conv_wgrad(dy, x, dw_oihw, ws, B, H, W, c_pad, Cin, Cout, KH, KW, stride, pad, ST, dbias);
+}
 int sbgm_colsum(const float* x, const float* y, float* out, int M, int C, void* stream) { return sbgm_launch_colsum(x, y, out, M, C, ST); }
 int sbgm_samplesum(const float* x, float* out, int B, int HW, int C, void* stream) { return sbgm_launch_samplesum(x, out, B, HW, C, ST); }
 int sbgm_groupnorm_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* skip, const float* tbias,

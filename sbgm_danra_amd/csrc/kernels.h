@@ -179,7 +179,8 @@ int sbgm_launch_sample_extremes(const float* x, int B, size_t per, float q, floa
 
 // ---- backward.hip (training path) ------------------------------------------------------------------------------------
 int sbgm_launch_conv_wgrad(const float* dy, const float* x, float* dw_oihw, float* dwp_ws, int B, int H, int W, int Cs, int Cin,
-                           int Cout, int KH, int KW, int S, int PAD, hipStream_t st);
+                           int Cout, int KH, int KW, int S, int PAD, hipStream_t st,
+                           float* dbias = nullptr);   // optional bias gradient [Cout] (zeroed by the launcher unless pre-zeroed)
 int sbgm_launch_colsum(const float* x, const float* y, float* out, int M, int C, hipStream_t st);
 int sbgm_launch_samplesum(const float* x, float* out, int B, int HW, int C, hipStream_t st);
 int sbgm_launch_groupnorm_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* skip,

@@ -211,13 +211,21 @@ class ConvFn(torch.autograd.Function):
                 N.check(_L().sbgm_conv_pack_weight_dgrad(w.data_ptr(), packed.data_ptr(), cout, cin, k, k, _st()))
             dx = torch.empty_like(x)
             _conv_launch(dy, packed, dx, cout, cin, k, 1, k - 1 - pad, in_dil=2 if stride == 2 else 0, out_hw=(H, W))
+        want_db = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             dw = torch.empty_like(w)
             ws, pooled = _zeros(k * k * cout * cs, x.device)
-            with _prezeroed(pooled):
-                N.check(_L().sbgm_conv2d_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), ws.data_ptr(), B, H, W, cs, cin, cout, k, k,
-                                               stride, pad, _st()))
-        if has_bias and ctx.needs_input_grad[2]:
+            if want_db and pooled:                               # bias gradient as a by-product of the weight-gradient sweep
+                db = torch.zeros(cout, device=x.device)          # a returned gradient: never a slice of the per-step pool
+                with _prezeroed(True):
+                    N.check(_L().sbgm_conv2d_wgrad_bias(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), B, H, W,
+                                                        cs, cin, cout, k, k, stride, pad, _st()))
+                want_db = False
+            else:
+                with _prezeroed(pooled):
+                    N.check(_L().sbgm_conv2d_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), ws.data_ptr(), B, H, W, cs, cin, cout, k, k,
+                                                   stride, pad, _st()))
+        if want_db:
             db = torch.empty(cout, device=x.device)
             N.check(_L().sbgm_colsum(dy.data_ptr(), None, db.data_ptr(), dy.numel() // cout, cout, _st()))
         dtb = None
