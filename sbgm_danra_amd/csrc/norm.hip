@@ -60,18 +60,6 @@ __global__ __launch_bounds__(NORM_THREADS) void norm_stats_kernel(const float* _
 }
 
 
-// sums -> (mean, rstd) as floats, once per statistic, so the streaming apply kernels stay HBM-bound
-__global__ void norm_finalize_kernel(const double* __restrict__ stats, float* __restrict__ mr, int n_stats, double inv_n,
-                                     float eps) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n_stats) {
-        const double mean = stats[2 * i] * inv_n;
-        const double var = fmax(stats[2 * i + 1] * inv_n - mean * mean, 0.0);
-        mr[2 * i] = (float)mean;
-        mr[2 * i + 1] = (float)(1.0 / sqrt(var + (double)eps));
-    }
-}
-
 // ---- GroupNorm pass 1: partial sums per (sample, chunk, group) -> stats[b][chunk][g][2] (doubles) -------------------
 constexpr int GN_MAX_CHUNKS = 64;
 constexpr int GN_APPLY_BLOCKS = 1024;   // blocks of the apply sweep over the whole batch; measured 128..16384: 1024 is best (each block re-reduces the chunk partials)
@@ -296,15 +284,24 @@ __global__ __launch_bounds__(256) void batchnorm_apply_kernel(const float* __res
     }
 }
 
-__global__ void batchnorm_running_kernel(float* running_mean, float* running_var, const double* stats, int C,
-                                         double n, float momentum) {
+// per-channel mean / rstd for the apply pass AND the running-statistics update, one launch (mean and biased variance are the
+// same expressions as before the merge, so the forward values and the running statistics are unchanged)
+__global__ void batchnorm_finalize_running_kernel(const double* __restrict__ stats, float* __restrict__ mr, float* running_mean,
+                                                  float* running_var, int C, double n, float eps, float momentum) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c < C) {
-        const double mean = stats[2 * c] / n;
-        const double var = fmax(stats[2 * c + 1] / n - mean * mean, 0.0);
-        const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        const double inv_n = 1.0 / n;
+        const double mean = stats[2 * c] * inv_n;
+        const double var = fmax(stats[2 * c + 1] * inv_n - mean * mean, 0.0);
+        mr[2 * c] = (float)mean;
+        mr[2 * c + 1] = (float)(1.0 / sqrt(var + (double)eps));
+        if (running_mean != nullptr) {
+            const double mean_r = stats[2 * c] / n;
+            const double var_r = fmax(stats[2 * c + 1] / n - mean_r * mean_r, 0.0);
+            const double unbiased = n > 1.0 ? var_r * n / (n - 1.0) : var_r;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean_r;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
     }
 }
 
@@ -370,15 +367,11 @@ int sbgm_launch_batchnorm_train(const float* x, float* y, const float* gamma, co
                        stats_ws, n, C, 1, ppb);
     SBGM_LAUNCH_CHECK();
     float* mr = reinterpret_cast<float*>(stats_ws + 2 * (size_t)C);
-    hipLaunchKernelGGL(norm_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, st, stats_ws, mr, C, 1.0 / (double)n, eps);
+    hipLaunchKernelGGL(batchnorm_finalize_running_kernel, dim3((C + 255) / 256), dim3(256), 0, st, stats_ws, mr, running_mean,
+                       running_var, C, (double)n, eps, momentum);
     SBGM_LAUNCH_CHECK();
     hipLaunchKernelGGL(batchnorm_apply_kernel, dim3(stream_blocks((size_t)n * (C / 4))), dim3(256), 0, st, x, y, gamma, beta,
                        res, tbias_after, relu, B, HW, C, mr);
     SBGM_LAUNCH_CHECK();
-    if (running_mean != nullptr) {
-        hipLaunchKernelGGL(batchnorm_running_kernel, dim3((C + 255) / 256), dim3(256), 0, st, running_mean, running_var,
-                           stats_ws, C, (double)n, momentum);
-        SBGM_LAUNCH_CHECK();
-    }
     return 0;
 }
