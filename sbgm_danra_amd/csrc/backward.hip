@@ -3,6 +3,7 @@
 // convolutions reuse conv_igemm.hip with transposed/flipped packed weights; this file holds the weight-gradient
 // GEMM, the normalisation / attention / resampling backward passes and the small reductions.
 // First version: correct and parity-tested; only the weight-gradient kernel is on the MFMA pipe.
+#include <cstdlib>
 #include "common.h"
 #include "kernels.h"
 
@@ -111,6 +112,109 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
                 const int co = co0 + 4 * (4 * kq + e) + i;
                 if (ci0 + 16 * j + r16 < Cs) atomicAdd(base + (size_t)co * Cs + ci0 + 16 * j + r16, acc[i][j][e]);
             }
+}
+
+// =====================================================================================================================
+// Weight gradient of a 3x3 / stride 1 / pad 1 convolution on maps >= 16 wide, LDS-staged (the layers that dominate the
+// backward pass: K = B*H*W pixels is long, Cout x Cin is small).  A workgroup owns a 64 x 64 (co x ci) block of ALL 9 taps
+// and walks over 4 x 16 pixel tiles of its share of the images: per tile it stages dy[64 px][64 co] and the halo patch
+// x[6 x 18 px][64 ci] in LDS once (16-byte global loads, zero padding from the buffer bounds check), then every wave
+// accumulates its 32 x 32 quarter of the 9 taps with fp32 MFMAs whose K index is the pixel: 2 + 18 LDS dword reads feed 36
+// MFMAs per 4-pixel step.  The wave-level kernel above re-reads dy 9x and x 9x from global memory and spends most of its
+// time on per-pixel index arithmetic; this one reads each operand once per (co, ci) block.  Partial sums of the workgroups
+// meet in the same [tap][Cout][Cs] slab through fp32 atomics (pre-zeroed), then unpack_wgrad_kernel writes OIHW.
+// Pixel stride in LDS = 80 floats: lanes (r16, kq) of a ds_read_b32 then fall on 32 distinct banks.
+// =====================================================================================================================
+constexpr int WG_TH = 4, WG_TW = 16, WG_PS = 80;   // tile rows / cols, LDS floats per pixel
+__global__ __launch_bounds__(256) void conv3x3_wgrad_lds_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                float* __restrict__ dwp, float* __restrict__ dbias, int B, int H,
+                                                                int W, int Cs, int Cout, int tiles_per_wg, uint32_t dy_bytes,
+                                                                uint32_t x_bytes) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* dys = reinterpret_cast<float*>(smem_raw);                   // [64 px][80]
+    float* xs = dys + WG_TH * WG_TW * WG_PS;                           // [6][18][80]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int n_ci = Cs / 64;
+    const int co0 = (blockIdx.x / n_ci) * 64, ci0 = (blockIdx.x % n_ci) * 64;
+    const int coh = (wave >> 1) * 32, cih = (wave & 1) * 32;            // this wave's quarter of the block
+    const int tiles_x = W / WG_TW, tiles_y = H / WG_TH, tiles_img = tiles_x * tiles_y, n_tiles = B * tiles_img;
+    const int t_begin = blockIdx.y * tiles_per_wg, t_end = min(n_tiles, t_begin + tiles_per_wg);
+    const __amdgpu_buffer_rsrc_t dr = make_rsrc(dy, dy_bytes);
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(x, x_bytes);
+
+    f32x4 acc[9][2][2];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = dbias != nullptr && ci0 == 0 && cih == 0;
+    float bsum[2] = {0.f, 0.f};
+
+    for (int t = t_begin; t < t_end; ++t) {
+        const int b = t / tiles_img, r = t - b * tiles_img;
+        const int y0 = (r / tiles_x) * WG_TH, x0 = (r % tiles_x) * WG_TW;
+        __syncthreads();                                              // the previous tile's reads are done
+        for (int q = tid; q < WG_TH * WG_TW * 16; q += 256) {          // dy tile: 64 px x 16 quads
+            const int px = q >> 4, c4 = (q & 15) * 4;
+            const int oy = y0 + (px >> 4), ox = x0 + (px & 15);
+            const f32x4 v = buf_load4(dr, (uint32_t)(((b * H + oy) * W + ox) * Cout + co0 + c4) * 4u);
+            *reinterpret_cast<f32x4*>(dys + px * WG_PS + c4) = v;
+        }
+        for (int q = tid; q < (WG_TH + 2) * (WG_TW + 2) * 16; q += 256) {   // x halo patch: 108 px x 16 quads
+            const int pp = q >> 4, c4 = (q & 15) * 4;
+            const int py = pp / (WG_TW + 2), pxx = pp - py * (WG_TW + 2);
+            const int iy = y0 - 1 + py, ix = x0 - 1 + pxx;
+            const bool ok = ((unsigned)iy < (unsigned)H) & ((unsigned)ix < (unsigned)W);
+            const f32x4 v = buf_load4(xr, ok ? (uint32_t)(((b * H + iy) * W + ix) * Cs + ci0 + c4) * 4u : 0x80000000u);
+            *reinterpret_cast<f32x4*>(xs + pp * WG_PS + c4) = v;
+        }
+        __syncthreads();
+#pragma unroll 2
+        for (int s = 0; s < WG_TH * WG_TW / 4; ++s) {                  // 16 steps of 4 pixels (4 consecutive columns of a row)
+            const int row = s >> 2, col = (s & 3) * 4 + kq;             // this lane's pixel = the MFMA k index
+            float a[2], bv[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) a[i] = dys[(row * WG_TW + col) * WG_PS + coh + 16 * i + r16];
+            if (do_bias) { bsum[0] += a[0]; bsum[1] += a[1]; }
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) {
+                    const float* xp = xs + ((row + kh) * (WG_TW + 2) + col + kw) * WG_PS + cih + r16;
+                    bv[0] = xp[0];
+                    bv[1] = xp[16];
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[kh * 3 + kw][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bv[j], acc[kh * 3 + kw][i][j], 0, 0, 0);
+                }
+        }
+    }
+    if (do_bias) {                                   // lane (r16, kq) summed channel coh+16i+r16 over its pixels: fold the 4 kq groups
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            bsum[i] += __shfl_xor(bsum[i], 16, 64);
+            bsum[i] += __shfl_xor(bsum[i], 32, 64);
+            if (kq == 0) atomicAdd(dbias + co0 + coh + 16 * i + r16, bsum[i]);
+        }
+    }
+    // D[row][col]: row = 4*kq + reg -> co, col = r16 -> ci
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        float* base = dwp + ((size_t)t * Cout) * Cs;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    atomicAdd(base + (size_t)(co0 + coh + 16 * i + 4 * kq + e) * Cs + ci0 + cih + 16 * j + r16, acc[t][i][j][e]);
+    }
 }
 
 // dwp [tap][Cout][Cs] -> OIHW [Cout][Cin][KH][KW]
@@ -687,6 +791,22 @@ int sbgm_launch_conv_wgrad(const float* dy, const float* x, float* dw_oihw, floa
     if (!sbgm_scratch_prezeroed) {
         SBGM_HIP(hipMemsetAsync(dwp_ws, 0, n * 4, st));
         if (dbias) SBGM_HIP(hipMemsetAsync(dbias, 0, (size_t)Cout * 4, st));
+    }
+    const size_t dy_b = (size_t)M * Cout * 4, x_b = (size_t)B * H * W * Cs * 4;
+    if (KH == 3 && KW == 3 && S == 1 && PAD == 1 && Cs % 64 == 0 && W % WG_TW == 0 && H % WG_TH == 0 && dy_b < (1ull << 31) &&
+        x_b < (1ull << 31) && getenv("SBGM_NO_LDS_WGRAD") == nullptr) {
+        const int blocks_x = (Cout / 64) * (Cs / 64);
+        const int n_tiles = B * (H / WG_TH) * (W / WG_TW);
+        const int wgs_y = std::max(1, std::min(n_tiles, (768 + blocks_x - 1) / blocks_x));      // ~3 workgroups per CU in total
+        const int tpw = (n_tiles + wgs_y - 1) / wgs_y;
+        const size_t lds = (size_t)(WG_TH * WG_TW + (WG_TH + 2) * (WG_TW + 2)) * WG_PS * 4;
+        hipLaunchKernelGGL(conv3x3_wgrad_lds_kernel, dim3(blocks_x, (n_tiles + tpw - 1) / tpw), dim3(256), lds, st, dy, x, dwp_ws, dbias,
+                           B, H, W, Cs, Cout, tpw, (uint32_t)dy_b, (uint32_t)x_b);
+        SBGM_LAUNCH_CHECK();
+        hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(stream_blocks((size_t)Cout * Cin * KH * KW)), dim3(256), 0, st, dwp_ws, dw_oihw, Cout,
+                           Cin, Cs, KH * KW);
+        SBGM_LAUNCH_CHECK();
+        return 0;
     }
     dim3 grid((tiles + 3) / 4, splits);
 #define SBGM_WG(F) hipLaunchKernelGGL(conv_wgrad_kernel<F>, grid, dim3(256), 0, st, dy, x, dwp_ws, B, H, W, Cs, OH, OW, Cout, KH, KW, S, PAD, pps, dbias)
