@@ -154,25 +154,48 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_lds_kernel(const float* __r
     const bool do_bias = dbias != nullptr && ci0 == 0 && cih == 0;
     float bsum[2] = {0.f, 0.f};
 
-    for (int t = t_begin; t < t_end; ++t) {
+    // register-staged double buffering: the global loads of tile t+1 are in flight while the matrix pipe works on tile t
+    constexpr int DYQ = WG_TH * WG_TW * 16 / 256;                      // 4 dy quads per thread
+    constexpr int XQ = ((WG_TH + 2) * (WG_TW + 2) * 16 + 255) / 256;   // 7 x quads per thread
+    f32x4 rdy[DYQ], rx[XQ];
+    auto tile_load = [&](int t) {
         const int b = t / tiles_img, r = t - b * tiles_img;
         const int y0 = (r / tiles_x) * WG_TH, x0 = (r % tiles_x) * WG_TW;
-        __syncthreads();                                              // the previous tile's reads are done
-        for (int q = tid; q < WG_TH * WG_TW * 16; q += 256) {          // dy tile: 64 px x 16 quads
+#pragma unroll
+        for (int u = 0; u < DYQ; ++u) {
+            const int q = tid + 256 * u;
             const int px = q >> 4, c4 = (q & 15) * 4;
             const int oy = y0 + (px >> 4), ox = x0 + (px & 15);
-            const f32x4 v = buf_load4(dr, (uint32_t)(((b * H + oy) * W + ox) * Cout + co0 + c4) * 4u);
-            *reinterpret_cast<f32x4*>(dys + px * WG_PS + c4) = v;
+            rdy[u] = buf_load4(dr, (uint32_t)(((b * H + oy) * W + ox) * Cout + co0 + c4) * 4u);
         }
-        for (int q = tid; q < (WG_TH + 2) * (WG_TW + 2) * 16; q += 256) {   // x halo patch: 108 px x 16 quads
+#pragma unroll
+        for (int u = 0; u < XQ; ++u) {
+            const int q = tid + 256 * u;
             const int pp = q >> 4, c4 = (q & 15) * 4;
             const int py = pp / (WG_TW + 2), pxx = pp - py * (WG_TW + 2);
             const int iy = y0 - 1 + py, ix = x0 - 1 + pxx;
-            const bool ok = ((unsigned)iy < (unsigned)H) & ((unsigned)ix < (unsigned)W);
-            const f32x4 v = buf_load4(xr, ok ? (uint32_t)(((b * H + iy) * W + ix) * Cs + ci0 + c4) * 4u : 0x80000000u);
-            *reinterpret_cast<f32x4*>(xs + pp * WG_PS + c4) = v;
+            const bool ok = (q < (WG_TH + 2) * (WG_TW + 2) * 16) & ((unsigned)iy < (unsigned)H) & ((unsigned)ix < (unsigned)W);
+            rx[u] = buf_load4(xr, ok ? (uint32_t)(((b * H + iy) * W + ix) * Cs + ci0 + c4) * 4u : 0x80000000u);
         }
+    };
+    auto tile_store = [&]() {
+#pragma unroll
+        for (int u = 0; u < DYQ; ++u) {
+            const int q = tid + 256 * u;
+            *reinterpret_cast<f32x4*>(dys + (q >> 4) * WG_PS + (q & 15) * 4) = rdy[u];
+        }
+#pragma unroll
+        for (int u = 0; u < XQ; ++u) {
+            const int q = tid + 256 * u;
+            if (q < (WG_TH + 2) * (WG_TW + 2) * 16) *reinterpret_cast<f32x4*>(xs + (q >> 4) * WG_PS + (q & 15) * 4) = rx[u];
+        }
+    };
+    if (t_begin < t_end) tile_load(t_begin);
+    for (int t = t_begin; t < t_end; ++t) {
+        __syncthreads();                                              // the previous tile's reads are done
+        tile_store();
         __syncthreads();
+        if (t + 1 < t_end) tile_load(t + 1);
 #pragma unroll 2
         for (int s = 0; s < WG_TH * WG_TW / 4; ++s) {                  // 16 steps of 4 pixels (4 consecutive columns of a row)
             const int row = s >> 2, col = (s & 3) * 4 + kq;             // this lane's pixel = the MFMA k index
