@@ -126,19 +126,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
 // Pixel stride in LDS = 80 floats: lanes (r16, kq) of a ds_read_b32 then fall on 32 distinct banks.
 // =====================================================================================================================
 constexpr int WG_TH = 4, WG_TW = 16, WG_PS = 80;   // tile rows / cols, LDS floats per pixel
-__global__ __launch_bounds__(256) void conv3x3_wgrad_lds_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                                float* __restrict__ dwp, float* __restrict__ dbias, int B, int H,
-                                                                int W, int Cs, int Cout, int tiles_per_wg, uint32_t dy_bytes,
-                                                                uint32_t x_bytes) {
+constexpr int WG_THREADS = 512;                    // 8 waves: 4 output quarters x 2 pixel groups
+__global__ __launch_bounds__(WG_THREADS) void conv3x3_wgrad_lds_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                       float* __restrict__ dwp, float* __restrict__ dbias, int B,
+                                                                       int H, int W, int Cs, int Cout, int tiles_per_wg,
+                                                                       uint32_t dy_bytes, uint32_t x_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* dys = reinterpret_cast<float*>(smem_raw);                   // [64 px][80]
     float* xs = dys + WG_TH * WG_TW * WG_PS;                           // [6][18][80]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int quarter = wave & 3, grp = wave >> 2;                     // grp: which half of the 4-pixel steps this wave takes
     const int r16 = lane & 15, kq = lane >> 4;
     const int n_ci = Cs / 64;
     const int co0 = (blockIdx.x / n_ci) * 64, ci0 = (blockIdx.x % n_ci) * 64;
-    const int coh = (wave >> 1) * 32, cih = (wave & 1) * 32;            // this wave's quarter of the block
+    const int coh = (quarter >> 1) * 32, cih = (quarter & 1) * 32;      // this wave's quarter of the block
     const int tiles_x = W / WG_TW, tiles_y = H / WG_TH, tiles_img = tiles_x * tiles_y, n_tiles = B * tiles_img;
     const int t_begin = blockIdx.y * tiles_per_wg, t_end = min(n_tiles, t_begin + tiles_per_wg);
     const __amdgpu_buffer_rsrc_t dr = make_rsrc(dy, dy_bytes);
@@ -155,22 +157,22 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_lds_kernel(const float* __r
     float bsum[2] = {0.f, 0.f};
 
     // register-staged double buffering: the global loads of tile t+1 are in flight while the matrix pipe works on tile t
-    constexpr int DYQ = WG_TH * WG_TW * 16 / 256;                      // 4 dy quads per thread
-    constexpr int XQ = ((WG_TH + 2) * (WG_TW + 2) * 16 + 255) / 256;   // 7 x quads per thread
+    constexpr int DYQ = WG_TH * WG_TW * 16 / WG_THREADS;                               // 2 dy quads per thread
+    constexpr int XQ = ((WG_TH + 2) * (WG_TW + 2) * 16 + WG_THREADS - 1) / WG_THREADS;   // 4 x quads per thread
     f32x4 rdy[DYQ], rx[XQ];
     auto tile_load = [&](int t) {
         const int b = t / tiles_img, r = t - b * tiles_img;
         const int y0 = (r / tiles_x) * WG_TH, x0 = (r % tiles_x) * WG_TW;
 #pragma unroll
         for (int u = 0; u < DYQ; ++u) {
-            const int q = tid + 256 * u;
+            const int q = tid + WG_THREADS * u;
             const int px = q >> 4, c4 = (q & 15) * 4;
             const int oy = y0 + (px >> 4), ox = x0 + (px & 15);
             rdy[u] = buf_load4(dr, (uint32_t)(((b * H + oy) * W + ox) * Cout + co0 + c4) * 4u);
         }
 #pragma unroll
         for (int u = 0; u < XQ; ++u) {
-            const int q = tid + 256 * u;
+            const int q = tid + WG_THREADS * u;
             const int pp = q >> 4, c4 = (q & 15) * 4;
             const int py = pp / (WG_TW + 2), pxx = pp - py * (WG_TW + 2);
             const int iy = y0 - 1 + py, ix = x0 - 1 + pxx;
@@ -181,12 +183,12 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_lds_kernel(const float* __r
     auto tile_store = [&]() {
 #pragma unroll
         for (int u = 0; u < DYQ; ++u) {
-            const int q = tid + 256 * u;
+            const int q = tid + WG_THREADS * u;
             *reinterpret_cast<f32x4*>(dys + (q >> 4) * WG_PS + (q & 15) * 4) = rdy[u];
         }
 #pragma unroll
         for (int u = 0; u < XQ; ++u) {
-            const int q = tid + 256 * u;
+            const int q = tid + WG_THREADS * u;
             if (q < (WG_TH + 2) * (WG_TW + 2) * 16) *reinterpret_cast<f32x4*>(xs + (q >> 4) * WG_PS + (q & 15) * 4) = rx[u];
         }
     };
@@ -197,7 +199,8 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_lds_kernel(const float* __r
         __syncthreads();
         if (t + 1 < t_end) tile_load(t + 1);
 #pragma unroll 2
-        for (int s = 0; s < WG_TH * WG_TW / 4; ++s) {                  // 16 steps of 4 pixels (4 consecutive columns of a row)
+        for (int sg = 0; sg < WG_TH * WG_TW / 8; ++sg) {               // this pixel group's 8 of the 16 steps of 4 pixels
+            const int s = 2 * sg + grp;
             const int row = s >> 2, col = (s & 3) * 4 + kq;             // this lane's pixel = the MFMA k index
             float a[2], bv[2];
 #pragma unroll
@@ -226,17 +229,33 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_lds_kernel(const float* __r
             if (kq == 0) atomicAdd(dbias + co0 + coh + 16 * i + r16, bsum[i]);
         }
     }
-    // D[row][col]: row = 4*kq + reg -> co, col = r16 -> ci
+    // Fold the two pixel groups through LDS tap by tap (the staging area is free now; two alternating 16 KB regions, one
+    // barrier per tap), so that only half of the waves send atomics: the atomic volume, not the matrix pipe, is what the
+    // epilogue costs.  D[row][col]: row = 4*kq + reg -> co, col = r16 -> ci
+    f32x4* red = reinterpret_cast<f32x4*>(smem_raw);                   // [2][4 quarters][4 (i,j)][64 lanes] x f32x4
+    __syncthreads();
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-        float* base = dwp + ((size_t)t * Cout) * Cs;
+        f32x4* slot = red + ((t & 1) * 4 + quarter) * 4 * 64 + lane;
+        if (grp == 1) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < 2; ++j) slot[(i * 2 + j) * 64] = acc[t][i][j];
+        }
+        __syncthreads();
+        if (grp == 0) {
+            float* base = dwp + ((size_t)t * Cout) * Cs;
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    atomicAdd(base + (size_t)(co0 + coh + 16 * i + 4 * kq + e) * Cs + ci0 + cih + 16 * j + r16, acc[t][i][j][e]);
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const f32x4 o = slot[(i * 2 + j) * 64];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        atomicAdd(base + (size_t)(co0 + coh + 16 * i + 4 * kq + e) * Cs + ci0 + cih + 16 * j + r16, acc[t][i][j][e] + o[e]);
+                }
+        }
     }
 }
 
@@ -820,10 +839,10 @@ int sbgm_launch_conv_wgrad(const float* dy, const float* x, float* dw_oihw, floa
         x_b < (1ull << 31) && getenv("SBGM_NO_LDS_WGRAD") == nullptr) {
         const int blocks_x = (Cout / 64) * (Cs / 64);
         const int n_tiles = B * (H / WG_TH) * (W / WG_TW);
-        const int wgs_y = std::max(1, std::min(n_tiles, (768 + blocks_x - 1) / blocks_x));      // ~3 workgroups per CU in total
+        const int wgs_y = std::max(1, std::min(n_tiles, (256 + blocks_x - 1) / blocks_x));      // one 8-wave workgroup per CU
         const int tpw = (n_tiles + wgs_y - 1) / wgs_y;
         const size_t lds = (size_t)(WG_TH * WG_TW + (WG_TH + 2) * (WG_TW + 2)) * WG_PS * 4;
-        hipLaunchKernelGGL(conv3x3_wgrad_lds_kernel, dim3(blocks_x, (n_tiles + tpw - 1) / tpw), dim3(256), lds, st, dy, x, dwp_ws, dbias,
+        hipLaunchKernelGGL(conv3x3_wgrad_lds_kernel, dim3(blocks_x, (n_tiles + tpw - 1) / tpw), dim3(WG_THREADS), lds, st, dy, x, dwp_ws, dbias,
                            B, H, W, Cs, Cout, tpw, (uint32_t)dy_b, (uint32_t)x_b);
         SBGM_LAUNCH_CHECK();
         hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(stream_blocks((size_t)Cout * Cin * KH * KW)), dim3(256), 0, st, dwp_ws, dw_oihw, Cout,
