@@ -115,33 +115,35 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
 }
 
 // =====================================================================================================================
-// Weight gradient of a 3x3 / stride 1 / pad 1 convolution on maps >= 16 wide, LDS-staged (the layers that dominate the
-// backward pass: K = B*H*W pixels is long, Cout x Cin is small).  A workgroup owns a 64 x 64 (co x ci) block of ALL 9 taps
-// and walks over 4 x 16 pixel tiles of its share of the images: per tile it stages dy[64 px][64 co] and the halo patch
-// x[6 x 18 px][64 ci] in LDS once (16-byte global loads, zero padding from the buffer bounds check), then every wave
-// accumulates its 32 x 32 quarter of the 9 taps with fp32 MFMAs whose K index is the pixel: 2 + 18 LDS dword reads feed 36
-// MFMAs per 4-pixel step.  The wave-level kernel above re-reads dy 9x and x 9x from global memory and spends most of its
-// time on per-pixel index arithmetic; this one reads each operand once per (co, ci) block.  Partial sums of the workgroups
-// meet in the same [tap][Cout][Cs] slab through fp32 atomics (pre-zeroed), then unpack_wgrad_kernel writes OIHW.
-// Pixel stride in LDS = 80 floats: lanes (r16, kq) of a ds_read_b32 then fall on 32 distinct banks.
+// Weight gradient of a 3x3 / stride 1 / pad 1 convolution on maps whose sides are multiples of 16, LDS-staged (the layers
+// that dominate the backward pass: K = B*H*W pixels is long, Cout x Cin is small).  A workgroup of 8 waves owns ONE
+// 32 x 32 (co x ci) block of all 9 taps and walks over 16 x 16 pixel tiles of its share of the images: per tile it stages
+// dy[256 px][32 co] and the halo patch x[18 x 18 px][32 ci] in LDS once (16-byte global loads, zero padding from the
+// buffer bounds check), then wave w accumulates rows 2w, 2w+1 of the tile into its own copy of the block with fp32 MFMAs
+// whose K index is the pixel: 2 + 18 LDS dword reads feed 36 MFMAs per 4-pixel step.  The wave-level kernel above re-reads
+// dy 9x and x 9x from global memory and spends most of its time on per-pixel index arithmetic.
+// The 8 copies are folded through LDS tap by tap, so one workgroup sends 36 KB of fp32 atomics into the pre-zeroed
+// [tap][Cout][Cs] slab, from which unpack_wgrad_kernel writes OIHW.  That volume is what the epilogue costs (the atomic
+// units take ~1.5 TB/s whatever the address pattern): with 64 x 64 blocks split over 4 quarter-waves it was 4x larger and
+// cost more than the matrix work at training batch sizes.
+// Pixel stride in LDS = 48 floats: lanes (r16, kq) of a ds_read_b32 then fall on 64 distinct banks.
 // =====================================================================================================================
-constexpr int WG_TH = 4, WG_TW = 16, WG_PS = 80;   // tile rows / cols, LDS floats per pixel
-constexpr int WG_THREADS = 512;                    // 8 waves: 4 output quarters x 2 pixel groups
+constexpr int WG_T = 16, WG_PS = 48;               // tile side, LDS floats per pixel
+constexpr int WG_THREADS = 512;                    // 8 waves = 8 pixel groups
+constexpr int WG_DY_FLOATS = WG_T * WG_T * WG_PS, WG_X_FLOATS = (WG_T + 2) * (WG_T + 2) * WG_PS;
 __global__ __launch_bounds__(WG_THREADS) void conv3x3_wgrad_lds_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                        float* __restrict__ dwp, float* __restrict__ dbias, int B,
                                                                        int H, int W, int Cs, int Cout, int tiles_per_wg,
                                                                        uint32_t dy_bytes, uint32_t x_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    float* dys = reinterpret_cast<float*>(smem_raw);                   // [64 px][80]
-    float* xs = dys + WG_TH * WG_TW * WG_PS;                           // [6][18][80]
+    float* dys = reinterpret_cast<float*>(smem_raw);                   // [256 px][48]
+    float* xs = dys + WG_DY_FLOATS;                                    // [18][18][48]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int quarter = wave & 3, grp = wave >> 2;                     // grp: which half of the 4-pixel steps this wave takes
     const int r16 = lane & 15, kq = lane >> 4;
-    const int n_ci = Cs / 64;
-    const int co0 = (blockIdx.x / n_ci) * 64, ci0 = (blockIdx.x % n_ci) * 64;
-    const int coh = (quarter >> 1) * 32, cih = (quarter & 1) * 32;      // this wave's quarter of the block
-    const int tiles_x = W / WG_TW, tiles_y = H / WG_TH, tiles_img = tiles_x * tiles_y, n_tiles = B * tiles_img;
+    const int n_ci = Cs / 32;
+    const int co0 = (blockIdx.x / n_ci) * 32, ci0 = (blockIdx.x % n_ci) * 32;
+    const int tiles_x = W / WG_T, tiles_y = H / WG_T, tiles_img = tiles_x * tiles_y, n_tiles = B * tiles_img;
     const int t_begin = blockIdx.y * tiles_per_wg, t_end = min(n_tiles, t_begin + tiles_per_wg);
     const __amdgpu_buffer_rsrc_t dr = make_rsrc(dy, dy_bytes);
     const __amdgpu_buffer_rsrc_t xr = make_rsrc(x, x_bytes);
@@ -153,30 +155,31 @@ __global__ __launch_bounds__(WG_THREADS) void conv3x3_wgrad_lds_kernel(const flo
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j) acc[t][i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bool do_bias = dbias != nullptr && ci0 == 0 && cih == 0;
+    const bool do_bias = dbias != nullptr && ci0 == 0;
     float bsum[2] = {0.f, 0.f};
 
     // register-staged double buffering: the global loads of tile t+1 are in flight while the matrix pipe works on tile t
-    constexpr int DYQ = WG_TH * WG_TW * 16 / WG_THREADS;                               // 2 dy quads per thread
-    constexpr int XQ = ((WG_TH + 2) * (WG_TW + 2) * 16 + WG_THREADS - 1) / WG_THREADS;   // 4 x quads per thread
+    constexpr int DY_QUADS = WG_T * WG_T * 8, X_QUADS = (WG_T + 2) * (WG_T + 2) * 8;
+    constexpr int DYQ = DY_QUADS / WG_THREADS;                          // 4 dy quads per thread
+    constexpr int XQ = (X_QUADS + WG_THREADS - 1) / WG_THREADS;         // 6 x quads per thread
     f32x4 rdy[DYQ], rx[XQ];
     auto tile_load = [&](int t) {
         const int b = t / tiles_img, r = t - b * tiles_img;
-        const int y0 = (r / tiles_x) * WG_TH, x0 = (r % tiles_x) * WG_TW;
+        const int y0 = (r / tiles_x) * WG_T, x0 = (r % tiles_x) * WG_T;
 #pragma unroll
         for (int u = 0; u < DYQ; ++u) {
             const int q = tid + WG_THREADS * u;
-            const int px = q >> 4, c4 = (q & 15) * 4;
+            const int px = q >> 3, c4 = (q & 7) * 4;
             const int oy = y0 + (px >> 4), ox = x0 + (px & 15);
             rdy[u] = buf_load4(dr, (uint32_t)(((b * H + oy) * W + ox) * Cout + co0 + c4) * 4u);
         }
 #pragma unroll
         for (int u = 0; u < XQ; ++u) {
             const int q = tid + WG_THREADS * u;
-            const int pp = q >> 4, c4 = (q & 15) * 4;
-            const int py = pp / (WG_TW + 2), pxx = pp - py * (WG_TW + 2);
+            const int pp = q >> 3, c4 = (q & 7) * 4;
+            const int py = pp / (WG_T + 2), pxx = pp - py * (WG_T + 2);
             const int iy = y0 - 1 + py, ix = x0 - 1 + pxx;
-            const bool ok = (q < (WG_TH + 2) * (WG_TW + 2) * 16) & ((unsigned)iy < (unsigned)H) & ((unsigned)ix < (unsigned)W);
+            const bool ok = (q < X_QUADS) & ((unsigned)iy < (unsigned)H) & ((unsigned)ix < (unsigned)W);
             rx[u] = buf_load4(xr, ok ? (uint32_t)(((b * H + iy) * W + ix) * Cs + ci0 + c4) * 4u : 0x80000000u);
         }
     };
@@ -184,12 +187,12 @@ __global__ __launch_bounds__(WG_THREADS) void conv3x3_wgrad_lds_kernel(const flo
 #pragma unroll
         for (int u = 0; u < DYQ; ++u) {
             const int q = tid + WG_THREADS * u;
-            *reinterpret_cast<f32x4*>(dys + (q >> 4) * WG_PS + (q & 15) * 4) = rdy[u];
+            *reinterpret_cast<f32x4*>(dys + (q >> 3) * WG_PS + (q & 7) * 4) = rdy[u];
         }
 #pragma unroll
         for (int u = 0; u < XQ; ++u) {
             const int q = tid + WG_THREADS * u;
-            if (q < (WG_TH + 2) * (WG_TW + 2) * 16) *reinterpret_cast<f32x4*>(xs + (q >> 4) * WG_PS + (q & 15) * 4) = rx[u];
+            if (q < X_QUADS) *reinterpret_cast<f32x4*>(xs + (q >> 3) * WG_PS + (q & 7) * 4) = rx[u];
         }
     };
     if (t_begin < t_end) tile_load(t_begin);
@@ -199,18 +202,17 @@ __global__ __launch_bounds__(WG_THREADS) void conv3x3_wgrad_lds_kernel(const flo
         __syncthreads();
         if (t + 1 < t_end) tile_load(t + 1);
 #pragma unroll 2
-        for (int sg = 0; sg < WG_TH * WG_TW / 8; ++sg) {               // this pixel group's 8 of the 16 steps of 4 pixels
-            const int s = 2 * sg + grp;
-            const int row = s >> 2, col = (s & 3) * 4 + kq;             // this lane's pixel = the MFMA k index
+        for (int s = 0; s < 8; ++s) {                                  // this wave's 2 rows: 8 steps of 4 consecutive pixels
+            const int row = 2 * wave + (s >> 2), col = (s & 3) * 4 + kq;   // this lane's pixel = the MFMA k index
             float a[2], bv[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = dys[(row * WG_TW + col) * WG_PS + coh + 16 * i + r16];
+            for (int i = 0; i < 2; ++i) a[i] = dys[(row * WG_T + col) * WG_PS + 16 * i + r16];
             if (do_bias) { bsum[0] += a[0]; bsum[1] += a[1]; }
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
                 for (int kw = 0; kw < 3; ++kw) {
-                    const float* xp = xs + ((row + kh) * (WG_TW + 2) + col + kw) * WG_PS + cih + r16;
+                    const float* xp = xs + ((row + kh) * (WG_T + 2) + col + kw) * WG_PS + r16;
                     bv[0] = xp[0];
                     bv[1] = xp[16];
 #pragma unroll
@@ -221,39 +223,44 @@ __global__ __launch_bounds__(WG_THREADS) void conv3x3_wgrad_lds_kernel(const flo
                 }
         }
     }
-    if (do_bias) {                                   // lane (r16, kq) summed channel coh+16i+r16 over its pixels: fold the 4 kq groups
+    if (do_bias) {                                   // lane (r16, kq) summed channel 16i+r16 over its pixels: fold the 4 kq groups
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             bsum[i] += __shfl_xor(bsum[i], 16, 64);
             bsum[i] += __shfl_xor(bsum[i], 32, 64);
-            if (kq == 0) atomicAdd(dbias + co0 + coh + 16 * i + r16, bsum[i]);
+            if (kq == 0) atomicAdd(dbias + co0 + 16 * i + r16, bsum[i]);
         }
     }
-    // Fold the two pixel groups through LDS tap by tap (the staging area is free now; two alternating 16 KB regions, one
-    // barrier per tap), so that only half of the waves send atomics: the atomic volume, not the matrix pipe, is what the
-    // epilogue costs.  D[row][col]: row = 4*kq + reg -> co, col = r16 -> ci
-    f32x4* red = reinterpret_cast<f32x4*>(smem_raw);                   // [2][4 quarters][4 (i,j)][64 lanes] x f32x4
+    // Fold the 8 copies through LDS tap by tap (the staging area is free now; two alternating 32 KB regions, one barrier per
+    // tap); wave t % 8 sums tap t and sends its atomics.  D[row][col]: row = 4*kq + reg -> co, col = r16 -> ci
+    f32x4* red = reinterpret_cast<f32x4*>(smem_raw);                   // [2][8 waves][4 (i,j)][64 lanes] x f32x4
     __syncthreads();
 #pragma unroll
     for (int t = 0; t < 9; ++t) {
-        f32x4* slot = red + ((t & 1) * 4 + quarter) * 4 * 64 + lane;
-        if (grp == 1) {
+        f32x4* region = red + (t & 1) * 8 * 4 * 64;
+        if (wave != (t & 7)) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) slot[(i * 2 + j) * 64] = acc[t][i][j];
+                for (int j = 0; j < 2; ++j) region[(wave * 4 + i * 2 + j) * 64 + lane] = acc[t][i][j];
         }
         __syncthreads();
-        if (grp == 0) {
+        if (wave == (t & 7)) {
             float* base = dwp + ((size_t)t * Cout) * Cs;
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const f32x4 o = slot[(i * 2 + j) * 64];
+                    f32x4 o = acc[t][i][j];
+#pragma unroll
+                    for (int w = 0; w < 8; ++w)
+                        if (w != (t & 7)) {
+                            const f32x4 v = region[(w * 4 + i * 2 + j) * 64 + lane];
+                            o[0] += v[0]; o[1] += v[1]; o[2] += v[2]; o[3] += v[3];
+                        }
 #pragma unroll
                     for (int e = 0; e < 4; ++e)
-                        atomicAdd(base + (size_t)(co0 + coh + 16 * i + 4 * kq + e) * Cs + ci0 + cih + 16 * j + r16, acc[t][i][j][e] + o[e]);
+                        atomicAdd(base + (size_t)(co0 + 16 * i + 4 * kq + e) * Cs + ci0 + 16 * j + r16, o[e]);
                 }
         }
     }
@@ -835,13 +842,19 @@ int sbgm_launch_conv_wgrad(const float* dy, const float* x, float* dw_oihw, floa
         if (dbias) SBGM_HIP(hipMemsetAsync(dbias, 0, (size_t)Cout * 4, st));
     }
     const size_t dy_b = (size_t)M * Cout * 4, x_b = (size_t)B * H * W * Cs * 4;
-    if (KH == 3 && KW == 3 && S == 1 && PAD == 1 && Cs % 64 == 0 && W % WG_TW == 0 && H % WG_TH == 0 && dy_b < (1ull << 31) &&
+    if (KH == 3 && KW == 3 && S == 1 && PAD == 1 && Cs % 32 == 0 && W % WG_T == 0 && H % WG_T == 0 && dy_b < (1ull << 31) &&
         x_b < (1ull << 31) && getenv("SBGM_NO_LDS_WGRAD") == nullptr) {
-        const int blocks_x = (Cout / 64) * (Cs / 64);
-        const int n_tiles = B * (H / WG_TH) * (W / WG_TW);
+        const int blocks_x = (Cout / 32) * (Cs / 32);
+        const int n_tiles = B * (H / WG_T) * (W / WG_T);
         const int wgs_y = std::max(1, std::min(n_tiles, (256 + blocks_x - 1) / blocks_x));      // one 8-wave workgroup per CU
         const int tpw = (n_tiles + wgs_y - 1) / wgs_y;
-        const size_t lds = (size_t)(WG_TH * WG_TW + (WG_TH + 2) * (WG_TW + 2)) * WG_PS * 4;
+        const size_t lds = (size_t)(WG_DY_FLOATS + WG_X_FLOATS) * 4;
+        static bool attr_set = false;
+        if (!attr_set) {
+            SBGM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_lds_kernel),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            attr_set = true;
+        }
         hipLaunchKernelGGL(conv3x3_wgrad_lds_kernel, dim3(blocks_x, (n_tiles + tpw - 1) / tpw), dim3(WG_THREADS), lds, st, dy, x, dwp_ws, dbias,
                            B, H, W, Cs, Cout, tpw, (uint32_t)dy_b, (uint32_t)x_b);
         SBGM_LAUNCH_CHECK();

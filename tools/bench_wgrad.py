@@ -1,3 +1,4 @@
+"""Per-layer microbenchmark of sbgm_conv2d_wgrad_bias (wgrad + unpack + the two memsets of the non-pooled path)."""
 import sys, torch
 from sbgm_danra_amd import _native as N
 L = N.lib()
@@ -15,7 +16,7 @@ def run(B, H, C, cout, reps=20):
     us = e0.elapsed_time(e1) / reps * 1e3
     fl = 2 * B * H * H * C * cout * 9
     print(f"B{B} H{H} C{C}->{cout}: {us:.1f} us  {fl/us/1e6:.1f} TF", flush=True)
-cfgs = [(8, 128, 64, 64), (8, 64, 128, 128), (8, 32, 256, 256), (8, 16, 512, 512), (8, 64, 256, 128), (8, 32, 512, 256)]
+cfgs = [(8, 64, 64, 64), (8, 32, 128, 128), (8, 16, 256, 256), (8, 64, 128, 64), (8, 32, 256, 128), (8, 16, 512, 256), (8, 128, 64, 64), (8, 64, 128, 128), (32, 64, 64, 64), (32, 16, 256, 256)]
 if len(sys.argv) > 1:
     cfgs = cfgs[:int(sys.argv[1])]
 for a in cfgs:
