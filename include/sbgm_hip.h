@@ -213,10 +213,12 @@ int sbgm_groupnorm_fwd(const float* x, float* y, const float* gamma, const float
                        float* mean_rstd_out /* [B,G,2] or NULL */, void* stream);
 /* nn.LayerNorm(C).  score_unet.py:128-129 */
 int sbgm_layernorm_fwd(const float* x, float* y, const float* gamma, const float* beta, int M, int C, float eps, void* stream);
-/* nn.BatchNorm2d in training mode (+ residual, ReLU, time bias).  stats_ws: >= 24*C bytes. */
+/* nn.BatchNorm2d in training mode (+ residual, ReLU, time bias).  stats_ws: >= 24*C bytes; its first 16*C bytes are the
+ * fp64 sums and must arrive zeroed when sbgm_set_scratch_prezeroed(1) is in force.  mean_rstd_out [C,2] (for
+ * sbgm_batchnorm_bwd) or NULL: the pairs are then left behind the sums, at stats_ws + 16*C bytes. */
 int sbgm_batchnorm_train_fwd(const float* x, float* y, const float* gamma, const float* beta, float* running_mean,
                              float* running_var, const float* residual, const float* tbias_after, int relu, int B, int HW,
-                             int C, float eps, float momentum, void* stats_ws, void* stream);
+                             int C, float eps, float momentum, void* stats_ws, float* mean_rstd_out, void* stream);
 /* Core of nn.MultiheadAttention between in_proj and out_proj: qkv [B,S,3C] -> [B,S,C].  score_unet.py:142 */
 int sbgm_mha_core_fwd(const float* qkv, float* out, int B, int S, int C, int heads, void* stream);
 /* SinusoidalEmbedding (+ label embedding) -> SiLU -> Linear, for one projection.  score_unet.py:41-45, :377-381 */

@@ -455,36 +455,67 @@ __global__ __launch_bounds__(256) void samplesum_kernel(const float* __restrict_
     }
 }
 
-// LayerNorm backward, one wave per token: dx = rstd*(g*gamma - mean(g*gamma) - xhat*mean(g*gamma*xhat));
-// dgamma/dbeta accumulated with atomics (token counts are small here: <= B*1024).
+// LayerNorm backward, one wave per token: dx = rstd*(g*gamma - mean(g*gamma) - xhat*mean(g*gamma*xhat)).
+// A wave walks over rows_per_wave tokens and keeps its lanes' dgamma/dbeta partial sums in registers (channel = lane + 64k);
+// the 4 waves of a block fold through LDS and send ONE atomic per (block, channel) — per-token atomics on the same C
+// addresses made this kernel 30 us per launch.
+constexpr int LN_MAX_K = 16;     // C <= 1024
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             const float* __restrict__ gamma, float* __restrict__ dx,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int C,
-                                                            float eps) {
-    const int lane = threadIdx.x & 63;
-    const int row = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    if (row >= M) return;
-    const float* xr = x + (size_t)row * C;
-    const float* gr = dy + (size_t)row * C;
-    float s = 0.f;
-    for (int c = lane; c < C; c += 64) s += xr[c];
-    const float mean = wave_sum(s) / (float)C;
-    float s2 = 0.f;
-    for (int c = lane; c < C; c += 64) { const float d = xr[c] - mean; s2 += d * d; }
-    const float rstd = 1.f / sqrtf(wave_sum(s2) / (float)C + eps);
-    float a1 = 0.f, a2 = 0.f;
-    for (int c = lane; c < C; c += 64) {
-        const float xh = (xr[c] - mean) * rstd, gg = gr[c] * gamma[c];
-        a1 += gg;
-        a2 += gg * xh;
+                                                            float eps, int rows_per_wave) {
+    extern __shared__ float ln_red[];                   // [4 waves][2][C]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row0 = (blockIdx.x * 4 + wave) * rows_per_wave, row1 = min(M, row0 + rows_per_wave);
+    float pg[LN_MAX_K], pb[LN_MAX_K];
+#pragma unroll
+    for (int k = 0; k < LN_MAX_K; ++k) pg[k] = pb[k] = 0.f;
+    for (int row = row0; row < row1; ++row) {
+        const float* xr = x + (size_t)row * C;
+        const float* gr = dy + (size_t)row * C;
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s += xr[c];
+        const float mean = wave_sum(s) / (float)C;
+        float s2 = 0.f;
+        for (int c = lane; c < C; c += 64) { const float d = xr[c] - mean; s2 += d * d; }
+        const float rstd = 1.f / sqrtf(wave_sum(s2) / (float)C + eps);
+        float a1 = 0.f, a2 = 0.f;
+        for (int c = lane; c < C; c += 64) {
+            const float xh = (xr[c] - mean) * rstd, gg = gr[c] * gamma[c];
+            a1 += gg;
+            a2 += gg * xh;
+        }
+        a1 = wave_sum(a1) / (float)C;
+        a2 = wave_sum(a2) / (float)C;
+#pragma unroll
+        for (int k = 0; k < LN_MAX_K; ++k) {
+            const int c = lane + 64 * k;
+            if (c < C) {
+                const float xh = (xr[c] - mean) * rstd, g = gr[c];
+                dx[(size_t)row * C + c] = rstd * (g * gamma[c] - a1 - xh * a2);
+                pg[k] += g * xh;
+                pb[k] += g;
+            }
+        }
     }
-    a1 = wave_sum(a1) / (float)C;
-    a2 = wave_sum(a2) / (float)C;
-    for (int c = lane; c < C; c += 64) {
-        const float xh = (xr[c] - mean) * rstd;
-        dx[(size_t)row * C + c] = rstd * (gr[c] * gamma[c] - a1 - xh * a2);
-        atomicAdd(dgamma + c, gr[c] * xh);
-        atomicAdd(dbeta + c, gr[c]);
+#pragma unroll
+    for (int k = 0; k < LN_MAX_K; ++k) {
+        const int c = lane + 64 * k;
+        if (c < C) {
+            ln_red[(wave * 2) * C + c] = pg[k];
+            ln_red[(wave * 2 + 1) * C + c] = pb[k];
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float g = 0.f, bsum = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            g += ln_red[(w * 2) * C + c];
+            bsum += ln_red[(w * 2 + 1) * C + c];
+        }
+        atomicAdd(dgamma + c, g);
+        atomicAdd(dbeta + c, bsum);
     }
 }
 
@@ -928,9 +959,16 @@ int sbgm_launch_batchnorm_bwd(const float* x, const float* dy, const float* y, c
 
 int sbgm_launch_layernorm_bwd(const float* x, const float* dy, const float* gamma, float* dx, float* dgamma, float* dbeta, int M, int C,
                               float eps, hipStream_t st) {
-    SBGM_HIP(hipMemsetAsync(dgamma, 0, (size_t)C * 4, st));
-    SBGM_HIP(hipMemsetAsync(dbeta, 0, (size_t)C * 4, st));
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((M + 3) / 4), dim3(256), 0, st, x, dy, gamma, dx, dgamma, dbeta, M, C, eps);
+    SBGM_CHECK(C <= 64 * LN_MAX_K, "layernorm_bwd: C=%d > %d", C, 64 * LN_MAX_K);
+    if (dbeta == dgamma + C) {                            // one [2][C] tensor: one memset
+        SBGM_HIP(hipMemsetAsync(dgamma, 0, (size_t)C * 8, st));
+    } else {
+        SBGM_HIP(hipMemsetAsync(dgamma, 0, (size_t)C * 4, st));
+        SBGM_HIP(hipMemsetAsync(dbeta, 0, (size_t)C * 4, st));
+    }
+    const int rpw = std::max(1, M / 1024);               // ~256 blocks of 4 waves
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((M + 4 * rpw - 1) / (4 * rpw)), dim3(256), (size_t)8 * C * sizeof(float), st, x, dy, gamma,
+                       dx, dgamma, dbeta, M, C, eps, rpw);
     SBGM_LAUNCH_CHECK();
     return 0;
 }

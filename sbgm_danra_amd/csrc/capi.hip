@@ -98,9 +98,9 @@ int sbgm_layernorm_fwd(const float* x, float* y, const float* gamma, const float
 }
 int sbgm_batchnorm_train_fwd(const float* x, float* y, const float* gamma, const float* beta, float* running_mean,
                              float* running_var, const float* residual, const float* tbias_after, int relu, int B, int HW,
-                             int C, float eps, float momentum, void* stats_ws, void* stream) {
+                             int C, float eps, float momentum, void* stats_ws, float* mean_rstd_out, void* stream) {
     return sbgm_launch_batchnorm_train(x, y, gamma, beta, running_mean, running_var, residual, tbias_after, relu, B, HW, C, eps,
-                                       momentum, (double*)stats_ws, ST);
+                                       momentum, (double*)stats_ws, ST, mean_rstd_out);
 }
 int sbgm_mha_core_fwd(const float* qkv, float* out, int B, int S, int C, int heads, void* stream) {
     return sbgm_launch_mha_core(qkv, out, B, S, C, heads, ST);

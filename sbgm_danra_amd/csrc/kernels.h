@@ -122,7 +122,8 @@ int sbgm_launch_layernorm(const float* x, float* y, const float* gamma, const fl
 // train-mode BatchNorm2d: batch statistics over (B,H,W), running-stat update, optional residual + ReLU
 int sbgm_launch_batchnorm_train(const float* x, float* y, const float* gamma, const float* beta, float* running_mean,
                                 float* running_var, const float* res, const float* tbias_after, int relu, int B,
-                                int HW, int C, float eps, float momentum, double* stats_ws, hipStream_t st);
+                                int HW, int C, float eps, float momentum, double* stats_ws, hipStream_t st,
+                                float* mr_out = nullptr);
 
 // ---- attention.hip -------------------------------------------------------------------------------------
 int sbgm_launch_mha_core(const float* qkv, float* out, int B, int S, int C, int heads, hipStream_t st);

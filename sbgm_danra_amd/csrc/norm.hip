@@ -354,9 +354,9 @@ int sbgm_launch_layernorm(const float* x, float* y, const float* gamma, const fl
 
 int sbgm_launch_batchnorm_train(const float* x, float* y, const float* gamma, const float* beta, float* running_mean,
                                 float* running_var, const float* res, const float* tbias_after, int relu, int B,
-                                int HW, int C, float eps, float momentum, double* stats_ws, hipStream_t st) {
+                                int HW, int C, float eps, float momentum, double* stats_ws, hipStream_t st, float* mr_out) {
     SBGM_CHECK(C % 4 == 0 && C <= 1024, "batchnorm: C=%d unsupported", C);
-    SBGM_HIP(hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * (size_t)C, st));
+    if (!sbgm_scratch_prezeroed) SBGM_HIP(hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * (size_t)C, st));
     // treat the batch as one long pixel axis: [B*HW][C]
     const int n = B * HW;
     const int lanes_px = std::max(1, NORM_THREADS / (C / 4));
@@ -366,7 +366,7 @@ int sbgm_launch_batchnorm_train(const float* x, float* y, const float* gamma, co
     hipLaunchKernelGGL(norm_stats_kernel<true>, dim3(chunks, 1), dim3(NORM_THREADS), 2 * C * sizeof(double), st, x,
                        stats_ws, n, C, 1, ppb);
     SBGM_LAUNCH_CHECK();
-    float* mr = reinterpret_cast<float*>(stats_ws + 2 * (size_t)C);
+    float* mr = mr_out ? mr_out : reinterpret_cast<float*>(stats_ws + 2 * (size_t)C);
     hipLaunchKernelGGL(batchnorm_finalize_running_kernel, dim3((C + 255) / 256), dim3(256), 0, st, stats_ws, mr, running_mean,
                        running_var, C, (double)n, eps, momentum);
     SBGM_LAUNCH_CHECK();

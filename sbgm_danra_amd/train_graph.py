@@ -250,26 +250,27 @@ class BNTrainFn(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, rm, rv, res, tb_after, relu, eps, momentum):
         B, H, W, Cc = x.shape
         y = torch.empty_like(x)
-        ws = torch.empty(24 * Cc + 64, dtype=torch.uint8, device=x.device)
-        N.check(_L().sbgm_batchnorm_train_fwd(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(),
-                                              rv.data_ptr(), N.ptr(res), N.ptr(tb_after), int(relu), B, H * W, Cc, eps, momentum,
-                                              ws.data_ptr(), _st()))
-        ctx.save_for_backward(x, y, gamma, tb_after, ws)
+        mr = torch.empty(Cc, 2, device=x.device)         # (mean, rstd) per channel, kept for the backward
+        sums, pooled = _zeros(4 * Cc, x.device)          # 2C fp64 sums: scratch of this launch only
+        with _prezeroed(pooled):
+            N.check(_L().sbgm_batchnorm_train_fwd(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(),
+                                                  rv.data_ptr(), N.ptr(res), N.ptr(tb_after), int(relu), B, H * W, Cc, eps, momentum,
+                                                  sums.data_ptr(), mr.data_ptr(), _st()))
+        ctx.save_for_backward(x, y, gamma, tb_after, mr)
         ctx.cfg = (relu, res is not None, tb_after is not None)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, gamma, tb_after, ws = ctx.saved_tensors
+        x, y, gamma, tb_after, mr = ctx.saved_tensors
         relu, has_res, has_tb = ctx.cfg
         dy = dy.contiguous()
         B, H, W, Cc = x.shape
         dx, dres = torch.empty_like(x), (torch.empty_like(x) if has_res else None)
         dg, db = torch.empty(Cc, device=x.device), torch.empty(Cc, device=x.device)
         s12, pooled = _zeros(B * Cc * 2, x.device)
-        mr = ws.data_ptr() + 16 * Cc                     # [C][2] floats behind the 2C doubles
         with _prezeroed(pooled):
-            N.check(_L().sbgm_batchnorm_bwd(x.data_ptr(), dy.data_ptr(), y.data_ptr(), gamma.data_ptr(), N.ptr(tb_after), mr, int(relu),
+            N.check(_L().sbgm_batchnorm_bwd(x.data_ptr(), dy.data_ptr(), y.data_ptr(), gamma.data_ptr(), N.ptr(tb_after), mr.data_ptr(), int(relu),
                                             dx.data_ptr(), N.ptr(dres), dg.data_ptr(), db.data_ptr(), s12.data_ptr(), B, H * W, Cc, _st()))
         dtb = None
         if has_tb:
@@ -328,7 +329,8 @@ class LayerNormFn(torch.autograd.Function):
         x, gamma = ctx.saved_tensors
         dy = dy.contiguous()
         M, Cc = x.shape
-        dx, dg, db = torch.empty_like(x), torch.empty(Cc, device=x.device), torch.empty(Cc, device=x.device)
+        dx, dgb = torch.empty_like(x), torch.empty(2, Cc, device=x.device)
+        dg, db = dgb[0], dgb[1]                          # adjacent: the launcher zeroes both with one memset
         N.check(_L().sbgm_layernorm_bwd(x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), M, Cc,
                                         ctx.eps, _st()))
         return dx, dg, db, None

@@ -104,14 +104,19 @@ def test_groupnorm_backward(Cc, G, act):
         assert maxrel(gd.grad.cpu(), gr.grad) < GT and maxrel(bd.grad.cpu(), br.grad) < GT
 
 
-def test_layernorm_act_upsample_backward():
-    M, Cc = 40, 256
+@pytest.mark.parametrize("M,Cc", [(40, 256), (2051, 128), (4096, 512), (7, 96), (3, 1024)])   # 1..4 rows per wave, ragged tails
+def test_layernorm_backward(M, Cc):
     x, g, b, go = rnd(M, Cc) * 2 + 1, rnd(Cc, seed=1), rnd(Cc, seed=2), rnd(M, Cc, seed=3)
     xr, gr, br = leaf(x), leaf(g), leaf(b)
     F.layer_norm(xr, (Cc,), gr, br, 1e-5).backward(go)
     xd, gd, bd = leaf(x, True), leaf(g, True), leaf(b, True)
     T.LayerNormFn.apply(xd, gd, bd, 1e-5).backward(go.cuda())
     assert maxrel(xd.grad.cpu(), xr.grad) < GT and maxrel(gd.grad.cpu(), gr.grad) < GT and maxrel(bd.grad.cpu(), br.grad) < GT
+
+
+def test_act_upsample_backward():
+    M, Cc = 40, 256
+    x, go = rnd(M, Cc) * 2 + 1, rnd(M, Cc, seed=3)
     xr = leaf(x)
     F.gelu(xr).backward(go)
     xd = leaf(x, True)

@@ -277,7 +277,7 @@ def test_batchnorm_train(with_res):
     y = torch.empty_like(xd)
     ws = torch.empty(24 * C_ + 64, dtype=torch.uint8, device=DEV)
     N.check(lib().sbgm_batchnorm_train_fwd(xd.data_ptr(), y.data_ptr(), gd.data_ptr(), bd.data_ptr(), rmd.data_ptr(), rvd.data_ptr(),
-                                           N.ptr(rd), N.ptr(td), int(with_res), B, H * W, C_, 1e-5, 0.1, ws.data_ptr(), N.stream()))
+                                           N.ptr(rd), N.ptr(td), int(with_res), B, H * W, C_, 1e-5, 0.1, ws.data_ptr(), None, N.stream()))
     assert relerr(nchw(y.cpu()), want) < 1e-5
     assert relerr(rmd.cpu(), rm_ref) < 1e-5 and relerr(rvd.cpu(), rv_ref) < 1e-5
 
