@@ -115,7 +115,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
 }
 
 // =====================================================================================================================
-// Weight gradient of a 3x3 / stride 1 / pad 1 convolution on maps whose sides are multiples of 16, LDS-staged (the layers
+// Weight gradient of a 3x3 / stride 1 / pad 1 convolution on maps whose sides are multiples of 16 (or 8 x 8), LDS-staged (the layers
 // that dominate the backward pass: K = B*H*W pixels is long, Cout x Cin is small).  A workgroup of 8 waves owns ONE
 // 32 x 32 (co x ci) block of all 9 taps and walks over 16 x 16 pixel tiles of its share of the images: per tile it stages
 // dy[256 px][32 co] and the halo patch x[18 x 18 px][32 ci] in LDS once (16-byte global loads, zero padding from the
@@ -128,22 +128,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
 // cost more than the matrix work at training batch sizes.
 // Pixel stride in LDS = 48 floats: lanes (r16, kq) of a ds_read_b32 then fall on 64 distinct banks.
 // =====================================================================================================================
-constexpr int WG_T = 16, WG_PS = 48;               // tile side, LDS floats per pixel
+constexpr int WG_PS = 48;                          // LDS floats per pixel
 constexpr int WG_THREADS = 512;                    // 8 waves = 8 pixel groups
-constexpr int WG_DY_FLOATS = WG_T * WG_T * WG_PS, WG_X_FLOATS = (WG_T + 2) * (WG_T + 2) * WG_PS;
+constexpr int WG_DY_FLOATS = 256 * WG_PS;
+// TW = 16: tiles are 16 x 16 pixels of one image.  TW = 8 (8 x 8 maps): a tile is 4 whole images stacked, each with its own
+// zero halo in the patch (4 x 10 rows of 10 pixels).
+template <int TW> struct WgTile {
+    static constexpr int PW = TW + 2, PH = TW == 16 ? 18 : 40, X_FLOATS = PH * PW * WG_PS;
+};
+template <int TW>
 __global__ __launch_bounds__(WG_THREADS) void conv3x3_wgrad_lds_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                        float* __restrict__ dwp, float* __restrict__ dbias, int B,
                                                                        int H, int W, int Cs, int Cout, int tiles_per_wg,
-                                                                       uint32_t dy_bytes, uint32_t x_bytes) {
+                                                                       uint32_t dy_bytes, uint32_t x_bytes, float* __restrict__ dw_direct,
+                                                                       int Cin) {
+    constexpr int PW = WgTile<TW>::PW, PH = WgTile<TW>::PH;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* dys = reinterpret_cast<float*>(smem_raw);                   // [256 px][48]
-    float* xs = dys + WG_DY_FLOATS;                                    // [18][18][48]
+    float* xs = dys + WG_DY_FLOATS;                                    // [PH][PW][48]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, kq = lane >> 4;
     const int n_ci = Cs / 32;
     const int co0 = (blockIdx.x / n_ci) * 32, ci0 = (blockIdx.x % n_ci) * 32;
-    const int tiles_x = W / WG_T, tiles_y = H / WG_T, tiles_img = tiles_x * tiles_y, n_tiles = B * tiles_img;
+    const int tiles_x = W / 16, tiles_img = tiles_x * (H / 16);        // TW = 16 only
+    const int n_tiles = TW == 16 ? B * tiles_img : (B + 3) / 4;
     const int t_begin = blockIdx.y * tiles_per_wg, t_end = min(n_tiles, t_begin + tiles_per_wg);
     const __amdgpu_buffer_rsrc_t dr = make_rsrc(dy, dy_bytes);
     const __amdgpu_buffer_rsrc_t xr = make_rsrc(x, x_bytes);
@@ -159,27 +168,39 @@ __global__ __launch_bounds__(WG_THREADS) void conv3x3_wgrad_lds_kernel(const flo
     float bsum[2] = {0.f, 0.f};
 
     // register-staged double buffering: the global loads of tile t+1 are in flight while the matrix pipe works on tile t
-    constexpr int DY_QUADS = WG_T * WG_T * 8, X_QUADS = (WG_T + 2) * (WG_T + 2) * 8;
+    constexpr int DY_QUADS = 256 * 8, X_QUADS = PH * PW * 8;
     constexpr int DYQ = DY_QUADS / WG_THREADS;                          // 4 dy quads per thread
-    constexpr int XQ = (X_QUADS + WG_THREADS - 1) / WG_THREADS;         // 6 x quads per thread
+    constexpr int XQ = (X_QUADS + WG_THREADS - 1) / WG_THREADS;         // 6 (7) x quads per thread
     f32x4 rdy[DYQ], rx[XQ];
     auto tile_load = [&](int t) {
-        const int b = t / tiles_img, r = t - b * tiles_img;
-        const int y0 = (r / tiles_x) * WG_T, x0 = (r % tiles_x) * WG_T;
+        int b0, y0 = 0, x0 = 0;
+        if (TW == 16) {
+            b0 = t / tiles_img;
+            const int r = t - b0 * tiles_img;
+            y0 = (r / tiles_x) * 16;
+            x0 = (r % tiles_x) * 16;
+        } else {
+            b0 = t * 4;
+        }
 #pragma unroll
         for (int u = 0; u < DYQ; ++u) {
             const int q = tid + WG_THREADS * u;
             const int px = q >> 3, c4 = (q & 7) * 4;
-            const int oy = y0 + (px >> 4), ox = x0 + (px & 15);
-            rdy[u] = buf_load4(dr, (uint32_t)(((b * H + oy) * W + ox) * Cout + co0 + c4) * 4u);
+            int b, oy, ox;
+            if (TW == 16) { b = b0; oy = y0 + (px >> 4); ox = x0 + (px & 15); }
+            else { b = b0 + (px >> 6); oy = (px >> 3) & 7; ox = px & 7; }
+            rdy[u] = buf_load4(dr, b < B ? (uint32_t)(((b * H + oy) * W + ox) * Cout + co0 + c4) * 4u : 0x80000000u);
         }
 #pragma unroll
         for (int u = 0; u < XQ; ++u) {
             const int q = tid + WG_THREADS * u;
             const int pp = q >> 3, c4 = (q & 7) * 4;
-            const int py = pp / (WG_T + 2), pxx = pp - py * (WG_T + 2);
-            const int iy = y0 - 1 + py, ix = x0 - 1 + pxx;
-            const bool ok = (q < X_QUADS) & ((unsigned)iy < (unsigned)H) & ((unsigned)ix < (unsigned)W);
+            const int py = pp / PW, pxx = pp - py * PW;
+            int b, iy;
+            if (TW == 16) { b = b0; iy = y0 - 1 + py; }
+            else { const int img = py / 10; b = b0 + img; iy = py - img * 10 - 1; }
+            const int ix = x0 - 1 + pxx;
+            const bool ok = (q < X_QUADS) & (b < B) & ((unsigned)iy < (unsigned)H) & ((unsigned)ix < (unsigned)W);
             rx[u] = buf_load4(xr, ok ? (uint32_t)(((b * H + iy) * W + ix) * Cs + ci0 + c4) * 4u : 0x80000000u);
         }
     };
@@ -202,17 +223,20 @@ __global__ __launch_bounds__(WG_THREADS) void conv3x3_wgrad_lds_kernel(const flo
         __syncthreads();
         if (t + 1 < t_end) tile_load(t + 1);
 #pragma unroll 2
-        for (int s = 0; s < 8; ++s) {                                  // this wave's 2 rows: 8 steps of 4 consecutive pixels
-            const int row = 2 * wave + (s >> 2), col = (s & 3) * 4 + kq;   // this lane's pixel = the MFMA k index
+        for (int s = 0; s < 8; ++s) {                                  // this wave's 32 pixels: 8 steps of 4 consecutive pixels
+            // this lane's pixel = the MFMA k index; prow = its row in the halo patch for kh = 0
+            const int row = TW == 16 ? 2 * wave + (s >> 2) : 4 * wave + (s >> 1);
+            const int col = (TW == 16 ? (s & 3) : (s & 1)) * 4 + kq;
+            const int prow = TW == 16 ? row : row + 2 * (row >> 3);
             float a[2], bv[2];
 #pragma unroll
-            for (int i = 0; i < 2; ++i) a[i] = dys[(row * WG_T + col) * WG_PS + 16 * i + r16];
+            for (int i = 0; i < 2; ++i) a[i] = dys[(row * TW + col) * WG_PS + 16 * i + r16];
             if (do_bias) { bsum[0] += a[0]; bsum[1] += a[1]; }
 #pragma unroll
             for (int kh = 0; kh < 3; ++kh)
 #pragma unroll
                 for (int kw = 0; kw < 3; ++kw) {
-                    const float* xp = xs + ((row + kh) * (WG_T + 2) + col + kw) * WG_PS + r16;
+                    const float* xp = xs + ((prow + kh) * PW + col + kw) * WG_PS + r16;
                     bv[0] = xp[0];
                     bv[1] = xp[16];
 #pragma unroll
@@ -258,9 +282,16 @@ __global__ __launch_bounds__(WG_THREADS) void conv3x3_wgrad_lds_kernel(const flo
                             const f32x4 v = region[(w * 4 + i * 2 + j) * 64 + lane];
                             o[0] += v[0]; o[1] += v[1]; o[2] += v[2]; o[3] += v[3];
                         }
+                    if (dw_direct) {                  // this workgroup is the only writer of its block: straight into OIHW
+                        const int ci = ci0 + 16 * j + r16;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        atomicAdd(base + (size_t)(co0 + 16 * i + 4 * kq + e) * Cs + ci0 + 16 * j + r16, o[e]);
+                        for (int e = 0; e < 4; ++e)
+                            if (ci < Cin) dw_direct[((size_t)(co0 + 16 * i + 4 * kq + e) * Cin + ci) * 9 + t] = o[e];
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            atomicAdd(base + (size_t)(co0 + 16 * i + 4 * kq + e) * Cs + ci0 + 16 * j + r16, o[e]);
+                    }
                 }
         }
     }
@@ -325,7 +356,8 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(NormBwdArgs a, int
     const int b = blockIdx.y;
     const int cq = a.C >> 2, cpg = a.C / a.G;
     const int q = threadIdx.x % cq, stripe = threadIdx.x / cq, lanes_px = 256 / cq;
-    if (stripe >= lanes_px) return;
+    __shared__ float red[256 * 8];                            // stripes fold here: one atomic per (block, channel, sum)
+    const bool active = stripe < lanes_px;
     const int c = q * 4;
     const int p0 = blockIdx.x * px_per_block, p1 = min(a.HW, p0 + px_per_block);
     f32x4 mean, rstd, gam = {1.f, 1.f, 1.f, 1.f}, bet = {0.f, 0.f, 0.f, 0.f}, tb = {0.f, 0.f, 0.f, 0.f};
@@ -339,7 +371,7 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(NormBwdArgs a, int
     if (a.tbias) tb = *reinterpret_cast<const f32x4*>(a.tbias + (size_t)b * a.C + c);
     f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = {0.f, 0.f, 0.f, 0.f};
     const size_t base = (size_t)b * a.HW * a.C + c;
-    for (int p = p0 + stripe; p < p1; p += lanes_px) {
+    for (int p = active ? p0 + stripe : p1; p < p1; p += lanes_px) {
         const size_t o = base + (size_t)p * a.C;
         const f32x4 xh = (*reinterpret_cast<const f32x4*>(a.x + o) - mean) * rstd;
         f32x4 g = *reinterpret_cast<const f32x4*>(a.dy + o);
@@ -359,10 +391,19 @@ __global__ __launch_bounds__(256) void norm_bwd_reduce_kernel(NormBwdArgs a, int
         s1 += g;
         s2 += g * xh;
     }
+    // red[stripe][c][2]
+    if (active) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        atomicAdd(a.s12 + ((size_t)b * a.C + c + e) * 2, s1[e]);
-        atomicAdd(a.s12 + ((size_t)b * a.C + c + e) * 2 + 1, s2[e]);
+        for (int e = 0; e < 4; ++e) {
+            red[(stripe * a.C + c + e) * 2] = s1[e];
+            red[(stripe * a.C + c + e) * 2 + 1] = s2[e];
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * a.C; i += 256) {
+        float t = 0.f;
+        for (int sidx = 0; sidx < lanes_px; ++sidx) t += red[sidx * 2 * a.C + i];
+        atomicAdd(a.s12 + (size_t)b * a.C * 2 + i, t);
     }
 }
 
@@ -864,36 +905,46 @@ int sbgm_launch_conv_wgrad(const float* dy, const float* x, float* dw_oihw, floa
     const int OH = (H + 2 * PAD - KH) / S + 1, OW = (W + 2 * PAD - KW) / S + 1, M = B * OH * OW;
     const int fci = Cs % 64 == 0 ? 4 : (Cs % 32 == 0 ? 2 : 1);
     const int tiles = KH * KW * (Cout / 64) * ((Cs + 16 * fci - 1) / (16 * fci));
-    int splits = std::max(1, std::min((M + 63) / 64, (4096 + tiles - 1) / tiles));   // measured: 1024 target waves is 14 % slower per step
+    static const int wtarget = getenv("SBGM_WG_TARGET") ? atoi(getenv("SBGM_WG_TARGET")) : 4096;
+    int splits = std::max(1, std::min((M + 63) / 64, (wtarget + tiles - 1) / tiles));   // measured: 1024 target waves is 14 % slower per step
     int pps = ((M + splits - 1) / splits + 3) / 4 * 4;
     splits = (M + pps - 1) / pps;
     const size_t n = (size_t)KH * KW * Cout * Cs;
-    if (!sbgm_scratch_prezeroed) {
-        SBGM_HIP(hipMemsetAsync(dwp_ws, 0, n * 4, st));
-        if (dbias) SBGM_HIP(hipMemsetAsync(dbias, 0, (size_t)Cout * 4, st));
-    }
+    if (!sbgm_scratch_prezeroed && dbias) SBGM_HIP(hipMemsetAsync(dbias, 0, (size_t)Cout * 4, st));
     const size_t dy_b = (size_t)M * Cout * 4, x_b = (size_t)B * H * W * Cs * 4;
-    if (KH == 3 && KW == 3 && S == 1 && PAD == 1 && Cs % 32 == 0 && W % WG_T == 0 && H % WG_T == 0 && dy_b < (1ull << 31) &&
-        x_b < (1ull << 31) && getenv("SBGM_NO_LDS_WGRAD") == nullptr) {
+    const bool lds16 = W % 16 == 0 && H % 16 == 0, lds8 = W == 8 && H == 8;
+    if (KH == 3 && KW == 3 && S == 1 && PAD == 1 && Cs % 32 == 0 && (lds16 || lds8) && dy_b < (1ull << 31) && x_b < (1ull << 31) &&
+        getenv("SBGM_NO_LDS_WGRAD") == nullptr) {
         const int blocks_x = (Cout / 32) * (Cs / 32);
-        const int n_tiles = B * (H / WG_T) * (W / WG_T);
+        const int n_tiles = lds16 ? B * (H / 16) * (W / 16) : (B + 3) / 4;
         const int wgs_y = std::max(1, std::min(n_tiles, (256 + blocks_x - 1) / blocks_x));      // one 8-wave workgroup per CU
         const int tpw = (n_tiles + wgs_y - 1) / wgs_y;
-        const size_t lds = (size_t)(WG_DY_FLOATS + WG_X_FLOATS) * 4;
+        const dim3 grid_lds(blocks_x, (n_tiles + tpw - 1) / tpw);
         static bool attr_set = false;
         if (!attr_set) {
-            SBGM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_lds_kernel),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            SBGM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_lds_kernel<16>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (WG_DY_FLOATS + WgTile<16>::X_FLOATS) * 4));
+            SBGM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_lds_kernel<8>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (WG_DY_FLOATS + WgTile<8>::X_FLOATS) * 4));
             attr_set = true;
         }
-        hipLaunchKernelGGL(conv3x3_wgrad_lds_kernel, dim3(blocks_x, (n_tiles + tpw - 1) / tpw), dim3(WG_THREADS), lds, st, dy, x, dwp_ws, dbias,
-                           B, H, W, Cs, Cout, tpw, (uint32_t)dy_b, (uint32_t)x_b);
+        float* direct = grid_lds.y == 1 ? dw_oihw : nullptr;          // no pixel split: no atomics, no slab, no unpack pass
+        if (!direct && !sbgm_scratch_prezeroed) SBGM_HIP(hipMemsetAsync(dwp_ws, 0, n * 4, st));
+        if (lds16)
+            hipLaunchKernelGGL(conv3x3_wgrad_lds_kernel<16>, grid_lds, dim3(WG_THREADS), (size_t)(WG_DY_FLOATS + WgTile<16>::X_FLOATS) * 4, st,
+                               dy, x, dwp_ws, dbias, B, H, W, Cs, Cout, tpw, (uint32_t)dy_b, (uint32_t)x_b, direct, Cin);
+        else
+            hipLaunchKernelGGL(conv3x3_wgrad_lds_kernel<8>, grid_lds, dim3(WG_THREADS), (size_t)(WG_DY_FLOATS + WgTile<8>::X_FLOATS) * 4, st,
+                               dy, x, dwp_ws, dbias, B, H, W, Cs, Cout, tpw, (uint32_t)dy_b, (uint32_t)x_b, direct, Cin);
         SBGM_LAUNCH_CHECK();
-        hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(stream_blocks((size_t)Cout * Cin * KH * KW)), dim3(256), 0, st, dwp_ws, dw_oihw, Cout,
-                           Cin, Cs, KH * KW);
-        SBGM_LAUNCH_CHECK();
+        if (!direct) {
+            hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(stream_blocks((size_t)Cout * Cin * KH * KW)), dim3(256), 0, st, dwp_ws, dw_oihw,
+                               Cout, Cin, Cs, KH * KW);
+            SBGM_LAUNCH_CHECK();
+        }
         return 0;
     }
+    if (!sbgm_scratch_prezeroed) SBGM_HIP(hipMemsetAsync(dwp_ws, 0, n * 4, st));
     dim3 grid((tiles + 3) / 4, splits);
 #define SBGM_WG(F) hipLaunchKernelGGL(conv_wgrad_kernel<F>, grid, dim3(256), 0, st, dy, x, dwp_ws, B, H, W, Cs, OH, OW, Cout, KH, KW, S, PAD, pps, dbias)
     if (fci == 4) SBGM_WG(4); else if (fci == 2) SBGM_WG(2); else SBGM_WG(1);
@@ -927,7 +978,7 @@ static int norm_bwd(bool bn, NormBwdArgs a, float* dgamma, float* dbeta, float* 
     SBGM_CHECK(a.C % 4 == 0 && a.C <= 1024, "norm_bwd: C=%d unsupported", a.C);
     if (!sbgm_scratch_prezeroed) SBGM_HIP(hipMemsetAsync(a.s12, 0, (size_t)a.B * a.C * 2 * 4, st));
     const int lanes_px = std::max(1, 256 / (a.C / 4));
-    int chunks = std::max(1, std::min(64, a.HW / (lanes_px * 16)));
+    int chunks = std::max(1, std::min(256, a.HW / (lanes_px * 4)));      // measured: 4 px per thread; 16 was 7 % slower per step
     const int ppb = (a.HW + chunks - 1) / chunks;
     chunks = (a.HW + ppb - 1) / ppb;
     if (bn) hipLaunchKernelGGL(norm_bwd_reduce_kernel<true>, dim3(chunks, a.B), dim3(256), 0, st, a, ppb);

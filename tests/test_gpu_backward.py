@@ -37,7 +37,9 @@ def leaf(t, dev=False):
 
 @pytest.mark.parametrize("B,Cin,H,Cout,k,s,p", [(2, 64, 8, 64, 3, 1, 1), (2, 64, 8, 128, 3, 2, 1), (2, 64, 8, 128, 1, 2, 0),
                                                  (1, 64, 16, 64, 8, 2, 3), (2, 128, 4, 64, 3, 1, 1), (1, 256, 2, 512, 3, 2, 1),
-                                                 (2, 64, 16, 64, 3, 1, 1), (1, 128, 32, 64, 3, 1, 1), (3, 64, 16, 128, 3, 1, 1)])   # LDS-staged wgrad
+                                                 (2, 64, 16, 64, 3, 1, 1), (1, 128, 32, 64, 3, 1, 1), (3, 64, 16, 128, 3, 1, 1),    # LDS-staged wgrad
+                                                 (5, 128, 8, 64, 3, 1, 1), (8, 64, 8, 64, 3, 1, 1), (1, 64, 8, 64, 3, 1, 1),      # ... 8 x 8 maps: 4 images per tile
+                                                 (9, 64, 16, 64, 3, 1, 1)])                                                      # several tiles per workgroup
 def test_conv_backward(B, Cin, H, Cout, k, s, p):
     x, w, b = rnd(B, Cin, H, H), rnd(Cout, Cin, k, k, seed=1, scale=1 / math.sqrt(Cin * k * k)), rnd(Cout, seed=2)
     res_shape = F.conv2d(x, w, b, s, p).shape
