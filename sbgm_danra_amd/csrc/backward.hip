@@ -339,6 +339,9 @@ struct NormBwdArgs {
     float* dres;           // gradient w.r.t. skip / residual, or null
     float* s12;            // workspace [B][C][2] (zeroed by the launcher)
     int B, HW, C, G, act, relu, has_res;
+    float* dgamma;         // [C] or null  (parameter gradients: written by block (0,0) of the apply pass from s12)
+    float* dbeta;          // [C] or null
+    float* dtbias;         // [B][C] or null (GroupNorm: the time bias sits inside the activation)
 };
 
 __device__ __forceinline__ float act_grad(float u, int act) {
@@ -434,6 +437,20 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(NormBwdArgs a) {
             for (int c = g * cpg; c < (g + 1) * cpg; ++c) { m12[2 * c] = t1 * inv_n; m12[2 * c + 1] = t2 * inv_n; }
         }
     }
+    if (blockIdx.x == 0 && blockIdx.y == 0) {
+        // from s12 [B][C][2]: dgamma[c] = sum_b s2, dbeta[c] = sum_b s1, dtbias[b][c] = s1
+        for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
+            float t1 = 0.f, t2 = 0.f;
+            for (int bb = 0; bb < a.B; ++bb) {
+                const float v1 = a.s12[((size_t)bb * a.C + c) * 2];
+                t1 += v1;
+                t2 += a.s12[((size_t)bb * a.C + c) * 2 + 1];
+                if (a.dtbias) a.dtbias[(size_t)bb * a.C + c] = v1;
+            }
+            if (a.dgamma) a.dgamma[c] = t2;
+            if (a.dbeta) a.dbeta[c] = t1;
+        }
+    }
     __syncthreads();
     const size_t per_sample = (size_t)a.HW * cq;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per_sample; i += (size_t)gridDim.x * blockDim.x) {
@@ -467,21 +484,6 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(NormBwdArgs a) {
         *reinterpret_cast<f32x4*>(a.dx + o) = dxv;
         if (a.dres) *reinterpret_cast<f32x4*>(a.dres + o) = g;
     }
-}
-
-// from s12 [B][C][2]: dgamma[c] = sum_b s2, dbeta[c] = sum_b s1, dtbias[b][c] = s1 (GroupNorm: time bias sits inside act)
-__global__ void norm_bwd_params_kernel(const float* __restrict__ s12, float* dgamma, float* dbeta, float* dtbias, int B, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float t1 = 0.f, t2 = 0.f;
-    for (int b = 0; b < B; ++b) {
-        const float v1 = s12[((size_t)b * C + c) * 2];
-        t1 += v1;
-        t2 += s12[((size_t)b * C + c) * 2 + 1];
-        if (dtbias) dtbias[(size_t)b * C + c] = v1;
-    }
-    if (dgamma) dgamma[c] = t2;
-    if (dbeta) dbeta[c] = t1;
 }
 
 // out[b][c] = sum_px x[b][px][c]   (time-bias gradients that sit OUTSIDE an activation: conv1 and BatchNorm-late adds)
@@ -814,28 +816,50 @@ __global__ __launch_bounds__(256) void cout1_bwd_data_kernel(const float* __rest
     }
 }
 
-// one block per (row-slab): accumulates dw[9][C] and dbias with atomics
+// One block per slab of input rows.  Thread = (channel quad, pixel stripe): every activation quad is read ONCE and feeds the 9
+// taps from registers (the 9 upstream-gradient values around it come from the cache); the stripes fold through LDS and the
+// block sends one atomic per (tap, channel).  The first version walked the slab once per (tap, channel) thread: 154 us.
 __global__ __launch_bounds__(256) void cout1_bwd_weight_kernel(const float* __restrict__ dout, const float* __restrict__ a,
                                                                const float* __restrict__ t, float sigma, float* __restrict__ dw,
                                                                float* __restrict__ dbias, int B, int H, int W, int C,
                                                                int rows_per_block) {
+    __shared__ float red[9 * 1024];                                  // [tap][stripe][C], stripes * C <= 1024
     const int nrows = B * H;
     const int r0 = blockIdx.x * rows_per_block, r1 = min(nrows, r0 + rows_per_block);
-    for (int idx = threadIdx.x; idx < 9 * C; idx += blockDim.x) {
-        const int tap = idx / C, c = idx - tap * C;
-        const int kh = tap / 3, kw = tap - kh * 3;
-        float s = 0.f;
+    const int cq = C >> 2, q = threadIdx.x % cq, stripe = threadIdx.x / cq, lanes_px = 256 / cq;
+    f32x4 acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (stripe < lanes_px) {
         for (int row = r0; row < r1; ++row) {
-            const int b = row / H, oy = row - b * H;
-            const int iy = oy + kh - 1;
-            if ((unsigned)iy >= (unsigned)H) continue;
+            const int b = row / H, iy = row - b * H;
             const float inv = t ? 1.f / sigma_of(t[b], sigma) : 1.f;
-            for (int ox = 0; ox < W; ++ox) {
-                const int ix = ox + kw - 1;
-                if ((unsigned)ix >= (unsigned)W) continue;
-                s = fmaf(a[(((size_t)b * H + iy) * W + ix) * C + c], dout[(size_t)row * W + ox] * inv, s);
+            const float* drow = dout + (size_t)b * H * W;
+            for (int ix = stripe; ix < W; ix += lanes_px) {
+                const f32x4 av = *reinterpret_cast<const f32x4*>(a + (((size_t)b * H + iy) * W + ix) * C + q * 4) * inv;
+#pragma unroll
+                for (int kh = 0; kh < 3; ++kh) {
+                    const int oy = iy - (kh - 1);                    // output pixel whose tap (kh, kw) reads input (iy, ix)
+                    if ((unsigned)oy >= (unsigned)H) continue;
+#pragma unroll
+                    for (int kw = 0; kw < 3; ++kw) {
+                        const int ox = ix - (kw - 1);
+                        if ((unsigned)ox >= (unsigned)W) continue;
+                        acc[kh * 3 + kw] += av * drow[(size_t)oy * W + ox];
+                    }
+                }
             }
         }
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) red[(k * lanes_px + stripe) * C + q * 4 + e] = acc[k][e];
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < 9 * C; idx += blockDim.x) {
+        const int tap = idx / C, c = idx - tap * C;
+        float s = 0.f;
+        for (int sidx = 0; sidx < lanes_px; ++sidx) s += red[(tap * lanes_px + sidx) * C + c];
         atomicAdd(dw + idx, s);
     }
     if (threadIdx.x < 64) {
@@ -977,6 +1001,9 @@ int sbgm_launch_samplesum(const float* x, float* out, int B, int HW, int C, hipS
 static int norm_bwd(bool bn, NormBwdArgs a, float* dgamma, float* dbeta, float* dtbias, hipStream_t st) {
     SBGM_CHECK(a.C % 4 == 0 && a.C <= 1024, "norm_bwd: C=%d unsupported", a.C);
     if (!sbgm_scratch_prezeroed) SBGM_HIP(hipMemsetAsync(a.s12, 0, (size_t)a.B * a.C * 2 * 4, st));
+    a.dgamma = dgamma;
+    a.dbeta = dbeta;
+    a.dtbias = dtbias;
     const int lanes_px = std::max(1, 256 / (a.C / 4));
     int chunks = std::max(1, std::min(256, a.HW / (lanes_px * 4)));      // measured: 4 px per thread; 16 was 7 % slower per step
     const int ppb = (a.HW + chunks - 1) / chunks;
@@ -988,8 +1015,6 @@ static int norm_bwd(bool bn, NormBwdArgs a, float* dgamma, float* dbeta, float* 
     const int bx = (int)std::max<size_t>(1, std::min<size_t>((per_sample + 255) / 256, 2048 / std::max(1, a.B) + 1));
     if (bn) hipLaunchKernelGGL(norm_bwd_apply_kernel<true>, dim3(bx, a.B), dim3(256), 2 * a.C * 4, st, a);
     else hipLaunchKernelGGL(norm_bwd_apply_kernel<false>, dim3(bx, a.B), dim3(256), 2 * a.C * 4, st, a);
-    SBGM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(norm_bwd_params_kernel, dim3((a.C + 255) / 256), dim3(256), 0, st, a.s12, dgamma, dbeta, dtbias, a.B, a.C);
     SBGM_LAUNCH_CHECK();
     return 0;
 }
@@ -1054,13 +1079,13 @@ int sbgm_launch_upsample2x_bwd(const float* dy, float* dx, int B, int H, int W, 
 
 int sbgm_launch_cout1_bwd(const float* dout, const float* a, const float* w_tap_c, const float* t, float sigma, float* da,
                           float* dw_tap_c, float* dbias, int B, int H, int W, int C, hipStream_t st) {
-    SBGM_CHECK(C % 4 == 0, "cout1_bwd: C=%d", C);
+    SBGM_CHECK(C % 4 == 0 && C <= 1024, "cout1_bwd: C=%d", C);
     hipLaunchKernelGGL(cout1_bwd_data_kernel, dim3(stream_blocks((size_t)B * H * W * (C / 4))), dim3(256), 0, st, dout, w_tap_c, t, sigma,
                        da, B, H, W, C);
     SBGM_LAUNCH_CHECK();
     SBGM_HIP(hipMemsetAsync(dw_tap_c, 0, (size_t)9 * C * 4, st));
     SBGM_HIP(hipMemsetAsync(dbias, 0, 4, st));
-    const int rows = B * H, rpb = std::max(1, rows / 1024);
+    const int rows = B * H, rpb = std::max(1, rows / 256);
     hipLaunchKernelGGL(cout1_bwd_weight_kernel, dim3((rows + rpb - 1) / rpb), dim3(256), 0, st, dout, a, t, sigma, dw_tap_c, dbias, B, H,
                        W, C, rpb);
     SBGM_LAUNCH_CHECK();

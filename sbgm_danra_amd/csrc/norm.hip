@@ -258,12 +258,36 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
 // y = relu?( (x - mean_c) * rsqrt(var_c + eps) * gamma + beta [+ res] ) [+ tbias_after[b]];  running stats get
 // momentum-weighted mean and UNBIASED variance, as torch.nn.BatchNorm2d does (used at score_unet.py:323 and in
 // every BasicBlock).
-__global__ __launch_bounds__(256) void batchnorm_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
-                                                              const float* __restrict__ gamma,
-                                                              const float* __restrict__ beta,
-                                                              const float* __restrict__ res,
-                                                              const float* __restrict__ tbias_after, int relu, int B,
-                                                              int HW, int C, const float* __restrict__ mr) {
+// Training-mode apply pass with the statistics finalisation folded in: every block derives the per-channel (mean, rstd) pairs
+// from the fp64 sums into LDS (same expressions as the former separate finalize launch, so forward values and running
+// statistics are unchanged); block 0 also stores the pairs for the backward pass and updates the running statistics.
+__global__ __launch_bounds__(256) void batchnorm_train_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                    const float* __restrict__ res, const float* __restrict__ tbias_after,
+                                                                    int relu, int B, int HW, int C, const double* __restrict__ stats,
+                                                                    float* __restrict__ mr, float* running_mean, float* running_var,
+                                                                    double n, float eps, float momentum) {
+    extern __shared__ float bn_ab[];                      // [C][2]: scale = rstd*gamma, shift = beta - mean*scale ... kept as (mean, rstd)
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const double inv_n = 1.0 / n;
+        const double mean = stats[2 * c] * inv_n;
+        const double var = fmax(stats[2 * c + 1] * inv_n - mean * mean, 0.0);
+        const float mf = (float)mean, rf = (float)(1.0 / sqrt(var + (double)eps));
+        bn_ab[2 * c] = mf;
+        bn_ab[2 * c + 1] = rf;
+        if (blockIdx.x == 0) {
+            mr[2 * c] = mf;
+            mr[2 * c + 1] = rf;
+            if (running_mean != nullptr) {
+                const double mean_r = stats[2 * c] / n;
+                const double var_r = fmax(stats[2 * c + 1] / n - mean_r * mean_r, 0.0);
+                const double unbiased = n > 1.0 ? var_r * n / (n - 1.0) : var_r;
+                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean_r;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+            }
+        }
+    }
+    __syncthreads();
     const int cq = C >> 2;
     const size_t total = (size_t)B * HW * cq;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -272,7 +296,7 @@ __global__ __launch_bounds__(256) void batchnorm_apply_kernel(const float* __res
         f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            v[e] = (v[e] - mr[2 * (c + e)]) * mr[2 * (c + e) + 1] * gamma[c + e] + beta[c + e];
+            v[e] = (v[e] - bn_ab[2 * (c + e)]) * bn_ab[2 * (c + e) + 1] * gamma[c + e] + beta[c + e];
         }
         if (res) v += reinterpret_cast<const f32x4*>(res)[i];
         if (relu) {
@@ -281,27 +305,6 @@ __global__ __launch_bounds__(256) void batchnorm_apply_kernel(const float* __res
         }
         if (tbias_after) v += *reinterpret_cast<const f32x4*>(tbias_after + (size_t)b * C + c);
         reinterpret_cast<f32x4*>(y)[i] = v;
-    }
-}
-
-// per-channel mean / rstd for the apply pass AND the running-statistics update, one launch (mean and biased variance are the
-// same expressions as before the merge, so the forward values and the running statistics are unchanged)
-__global__ void batchnorm_finalize_running_kernel(const double* __restrict__ stats, float* __restrict__ mr, float* running_mean,
-                                                  float* running_var, int C, double n, float eps, float momentum) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c < C) {
-        const double inv_n = 1.0 / n;
-        const double mean = stats[2 * c] * inv_n;
-        const double var = fmax(stats[2 * c + 1] * inv_n - mean * mean, 0.0);
-        mr[2 * c] = (float)mean;
-        mr[2 * c + 1] = (float)(1.0 / sqrt(var + (double)eps));
-        if (running_mean != nullptr) {
-            const double mean_r = stats[2 * c] / n;
-            const double var_r = fmax(stats[2 * c + 1] / n - mean_r * mean_r, 0.0);
-            const double unbiased = n > 1.0 ? var_r * n / (n - 1.0) : var_r;
-            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean_r;
-            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
-        }
     }
 }
 
@@ -367,11 +370,8 @@ int sbgm_launch_batchnorm_train(const float* x, float* y, const float* gamma, co
                        stats_ws, n, C, 1, ppb);
     SBGM_LAUNCH_CHECK();
     float* mr = mr_out ? mr_out : reinterpret_cast<float*>(stats_ws + 2 * (size_t)C);
-    hipLaunchKernelGGL(batchnorm_finalize_running_kernel, dim3((C + 255) / 256), dim3(256), 0, st, stats_ws, mr, running_mean,
-                       running_var, C, (double)n, eps, momentum);
-    SBGM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(batchnorm_apply_kernel, dim3(stream_blocks((size_t)n * (C / 4))), dim3(256), 0, st, x, y, gamma, beta,
-                       res, tbias_after, relu, B, HW, C, mr);
+    hipLaunchKernelGGL(batchnorm_train_apply_kernel, dim3(stream_blocks((size_t)n * (C / 4))), dim3(256), 2 * C * sizeof(float), st, x, y,
+                       gamma, beta, res, tbias_after, relu, B, HW, C, stats_ws, mr, running_mean, running_var, (double)n, eps, momentum);
     SBGM_LAUNCH_CHECK();
     return 0;
 }
