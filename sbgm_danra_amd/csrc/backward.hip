@@ -297,6 +297,127 @@ __global__ __launch_bounds__(WG_THREADS) void conv3x3_wgrad_lds_kernel(const flo
     }
 }
 
+// =====================================================================================================================
+// Weight gradient of a 1x1 convolution (stride 1 or 2) and of nn.Linear over tokens: the split-K GEMM
+// dW[co][ci] = sum_m dy[m][co] * x[pixel(m)][ci], LDS-staged.  A workgroup of 8 waves owns one 64 x 64 block; per tile of
+// 128 output pixels it stages dy[128][64] and x[128][64] once, wave w takes pixels 16w..16w+15 (4 MFMA k-steps) and keeps
+// its own 64 x 64 partial block (16 accumulator quads: 8 LDS dword reads feed 16 MFMAs, 128 staged bytes per MFMA).  The 8
+// partial blocks fold through LDS; one atomic (or, without a pixel split, one plain OIHW store) per element and workgroup.
+// =====================================================================================================================
+constexpr int W1_PX = 128, W1_PS = 80;             // pixels per tile, LDS floats per pixel (64 channels + pad: conflict-free)
+__global__ __launch_bounds__(WG_THREADS) void conv1x1_wgrad_lds_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                       float* __restrict__ dwp, float* __restrict__ dbias, int Mo,
+                                                                       int OH, int OW, int H, int W, int stride, int Cs, int Cout,
+                                                                       int tiles_per_wg, uint32_t dy_bytes, uint32_t x_bytes,
+                                                                       float* __restrict__ dw_direct, int Cin) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* dys = reinterpret_cast<float*>(smem_raw);                   // [128 px][80]
+    float* xs = dys + W1_PX * W1_PS;                                   // [128 px][80]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int n_ci = Cs / 64;
+    const int co0 = (blockIdx.x / n_ci) * 64, ci0 = (blockIdx.x % n_ci) * 64;
+    const int n_tiles = (Mo + W1_PX - 1) / W1_PX;
+    const int t_begin = blockIdx.y * tiles_per_wg, t_end = min(n_tiles, t_begin + tiles_per_wg);
+    const __amdgpu_buffer_rsrc_t dr = make_rsrc(dy, dy_bytes);
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(x, x_bytes);
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = dbias != nullptr && ci0 == 0;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+
+    constexpr int QPT = W1_PX * 16 / WG_THREADS;                       // 4 quads of each operand per thread
+    f32x4 rdy[QPT], rx[QPT];
+    auto tile_load = [&](int t) {
+#pragma unroll
+        for (int u = 0; u < QPT; ++u) {
+            const int q = tid + WG_THREADS * u;
+            const int p = t * W1_PX + (q >> 4), c4 = (q & 15) * 4;
+            int ip = p;
+            if (stride != 1) {
+                const int b = p / (OH * OW), r = p - b * (OH * OW);
+                const int oy = r / OW, ox = r - oy * OW;
+                ip = (b * H + oy * stride) * W + ox * stride;
+            }
+            const bool ok = p < Mo;
+            rdy[u] = buf_load4(dr, ok ? (uint32_t)(p * Cout + co0 + c4) * 4u : 0x80000000u);
+            rx[u] = buf_load4(xr, ok ? (uint32_t)(ip * Cs + ci0 + c4) * 4u : 0x80000000u);
+        }
+    };
+    auto tile_store = [&]() {
+#pragma unroll
+        for (int u = 0; u < QPT; ++u) {
+            const int q = tid + WG_THREADS * u;
+            *reinterpret_cast<f32x4*>(dys + (q >> 4) * W1_PS + (q & 15) * 4) = rdy[u];
+            *reinterpret_cast<f32x4*>(xs + (q >> 4) * W1_PS + (q & 15) * 4) = rx[u];
+        }
+    };
+    if (t_begin < t_end) tile_load(t_begin);
+    for (int t = t_begin; t < t_end; ++t) {
+        __syncthreads();                                              // the previous tile's reads are done
+        tile_store();
+        __syncthreads();
+        if (t + 1 < t_end) tile_load(t + 1);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {                                  // this wave's 16 pixels: 4 steps of 4 pixels
+            const int px = 16 * wave + 4 * s + kq;                      // this lane's pixel = the MFMA k index
+            float a[4], bv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                a[i] = dys[px * W1_PS + 16 * i + r16];
+                bv[i] = xs[px * W1_PS + 16 * i + r16];
+            }
+            if (do_bias) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bsum[i] += a[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bsum[i] += __shfl_xor(bsum[i], 16, 64);
+            bsum[i] += __shfl_xor(bsum[i], 32, 64);
+            if (kq == 0) atomicAdd(dbias + co0 + 16 * i + r16, bsum[i]);
+        }
+    }
+    // Fold the 8 partial blocks through LDS in two halves of 8 sub-blocks (64 KB each): every wave stores its copy of the
+    // half, then wave w sums sub-block w of it over the 8 copies.  D[row][col]: row = 4*kq + reg -> co, col = r16 -> ci
+    f32x4* red = reinterpret_cast<f32x4*>(smem_raw);                   // [8 waves][8 sub-blocks][64 lanes] x f32x4
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        __syncthreads();                                              // staging reads / the previous half's reads are done
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) red[(wave * 8 + i * 4 + j) * 64 + lane] = acc[2 * h + i][j];
+        __syncthreads();
+        f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int w = 0; w < 8; ++w) {
+            const f32x4 v = red[(w * 8 + wave) * 64 + lane];
+            o[0] += v[0]; o[1] += v[1]; o[2] += v[2]; o[3] += v[3];
+        }
+        const int i = 2 * h + (wave >> 2), j = wave & 3;
+        const int ci = ci0 + 16 * j + r16;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int co = co0 + 16 * i + 4 * kq + e;
+            if (dw_direct) { if (ci < Cin) dw_direct[(size_t)co * Cin + ci] = o[e]; }
+            else atomicAdd(dwp + (size_t)co * Cs + ci, o[e]);
+        }
+    }
+}
+
 // dwp [tap][Cout][Cs] -> OIHW [Cout][Cin][KH][KW]
 __global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int Cout, int Cin, int Cs, int taps) {
     const size_t total = (size_t)Cout * Cin * taps;
@@ -936,6 +1057,32 @@ int sbgm_launch_conv_wgrad(const float* dy, const float* x, float* dw_oihw, floa
     const size_t n = (size_t)KH * KW * Cout * Cs;
     if (!sbgm_scratch_prezeroed && dbias) SBGM_HIP(hipMemsetAsync(dbias, 0, (size_t)Cout * 4, st));
     const size_t dy_b = (size_t)M * Cout * 4, x_b = (size_t)B * H * W * Cs * 4;
+    if (KH == 1 && KW == 1 && PAD == 0 && (S == 1 || S == 2) && Cs % 64 == 0 && dy_b < (1ull << 31) && x_b < (1ull << 31) &&
+        getenv("SBGM_NO_LDS_WGRAD") == nullptr) {
+        const int blocks_x = (Cout / 64) * (Cs / 64);
+        const int n_tiles = (M + W1_PX - 1) / W1_PX;
+        const int wgs_y = std::max(1, std::min(n_tiles, (256 + blocks_x - 1) / blocks_x));      // one 8-wave workgroup per CU
+        const int tpw = (n_tiles + wgs_y - 1) / wgs_y;
+        const dim3 grid_lds(blocks_x, (n_tiles + tpw - 1) / tpw);
+        const size_t lds = (size_t)2 * W1_PX * W1_PS * 4;
+        static bool attr1_set = false;
+        if (!attr1_set) {
+            SBGM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_wgrad_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds));
+            attr1_set = true;
+        }
+        float* direct = grid_lds.y == 1 ? dw_oihw : nullptr;
+        if (!direct && !sbgm_scratch_prezeroed) SBGM_HIP(hipMemsetAsync(dwp_ws, 0, n * 4, st));
+        hipLaunchKernelGGL(conv1x1_wgrad_lds_kernel, grid_lds, dim3(WG_THREADS), lds, st, dy, x, dwp_ws, dbias, M, OH, OW, H, W, S, Cs, Cout,
+                           tpw, (uint32_t)dy_b, (uint32_t)x_b, direct, Cin);
+        SBGM_LAUNCH_CHECK();
+        if (!direct) {
+            hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(stream_blocks((size_t)Cout * Cin)), dim3(256), 0, st, dwp_ws, dw_oihw, Cout, Cin, Cs,
+                               1);
+            SBGM_LAUNCH_CHECK();
+        }
+        return 0;
+    }
     const bool lds16 = W % 16 == 0 && H % 16 == 0, lds8 = W == 8 && H == 8;
     if (KH == 3 && KW == 3 && S == 1 && PAD == 1 && Cs % 32 == 0 && (lds16 || lds8) && dy_b < (1ull << 31) && x_b < (1ull << 31) &&
         getenv("SBGM_NO_LDS_WGRAD") == nullptr) {

@@ -39,7 +39,9 @@ def leaf(t, dev=False):
                                                  (1, 64, 16, 64, 8, 2, 3), (2, 128, 4, 64, 3, 1, 1), (1, 256, 2, 512, 3, 2, 1),
                                                  (2, 64, 16, 64, 3, 1, 1), (1, 128, 32, 64, 3, 1, 1), (3, 64, 16, 128, 3, 1, 1),    # LDS-staged wgrad
                                                  (5, 128, 8, 64, 3, 1, 1), (8, 64, 8, 64, 3, 1, 1), (1, 64, 8, 64, 3, 1, 1),      # ... 8 x 8 maps: 4 images per tile
-                                                 (9, 64, 16, 64, 3, 1, 1)])                                                      # several tiles per workgroup
+                                                 (9, 64, 16, 64, 3, 1, 1),                                                       # several tiles per workgroup
+                                                 (3, 128, 16, 64, 1, 1, 0), (1, 64, 6, 128, 1, 1, 0), (2, 192, 10, 64, 1, 2, 0),  # LDS-staged 1x1 (pixel split / ragged tile / stride 2)
+                                                 (8, 64, 32, 64, 1, 1, 0)])
 def test_conv_backward(B, Cin, H, Cout, k, s, p):
     x, w, b = rnd(B, Cin, H, H), rnd(Cout, Cin, k, k, seed=1, scale=1 / math.sqrt(Cin * k * k)), rnd(Cout, seed=2)
     res_shape = F.conv2d(x, w, b, s, p).shape
