@@ -191,7 +191,8 @@ typedef struct sbgm_pack_desc {
     int Cout, Cin, KH, KW, cs, nsteps, transposed, block_begin;
 } sbgm_pack_desc;
 int sbgm_conv_pack_weights_batched(const sbgm_pack_desc* desc_dev, int n, int total_blocks, void* stream);
-/* Process-wide switch for the backward launchers (sbgm_conv2d_wgrad, sbgm_groupnorm_bwd, sbgm_batchnorm_bwd): 1 = the caller
+/* Process-wide switch for the backward launchers (sbgm_conv2d_wgrad[_bias], sbgm_groupnorm_bwd, sbgm_batchnorm_bwd,
+ * sbgm_layernorm_bwd's dgamma/dbeta, sbgm_samplesum's output, sbgm_batchnorm_train_fwd's sums): 1 = the caller
  * hands in already-zeroed scratch and the launchers skip their own memsets.  Returns the previous value. */
 int sbgm_set_scratch_prezeroed(int on);
 /* Winograd F(2,3)-along-rows weight transform for 3x3 kernels: OIHW -> U[kh][c/16][xi][Cout][16] */

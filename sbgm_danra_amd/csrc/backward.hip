@@ -1137,7 +1137,7 @@ int sbgm_launch_colsum(const float* x, const float* y, float* out, int M, int C,
 }
 
 int sbgm_launch_samplesum(const float* x, float* out, int B, int HW, int C, hipStream_t st) {
-    SBGM_HIP(hipMemsetAsync(out, 0, (size_t)B * C * 4, st));
+    if (!sbgm_scratch_prezeroed) SBGM_HIP(hipMemsetAsync(out, 0, (size_t)B * C * 4, st));
     const int chunks = std::max(1, std::min(64, HW / 64));
     const int ppb = (HW + chunks - 1) / chunks;
     hipLaunchKernelGGL(samplesum_kernel, dim3((HW + ppb - 1) / ppb, B), dim3(256), 0, st, x, out, HW, C, ppb);
@@ -1183,7 +1183,8 @@ int sbgm_launch_batchnorm_bwd(const float* x, const float* dy, const float* y, c
 int sbgm_launch_layernorm_bwd(const float* x, const float* dy, const float* gamma, float* dx, float* dgamma, float* dbeta, int M, int C,
                               float eps, hipStream_t st) {
     SBGM_CHECK(C <= 64 * LN_MAX_K, "layernorm_bwd: C=%d > %d", C, 64 * LN_MAX_K);
-    if (dbeta == dgamma + C) {                            // one [2][C] tensor: one memset
+    if (sbgm_scratch_prezeroed) {
+    } else if (dbeta == dgamma + C) {                     // one [2][C] tensor: one memset
         SBGM_HIP(hipMemsetAsync(dgamma, 0, (size_t)C * 8, st));
     } else {
         SBGM_HIP(hipMemsetAsync(dgamma, 0, (size_t)C * 4, st));

@@ -58,6 +58,25 @@ def _zero_reset(dev):
         z = _ZERO[dev] = [torch.empty(_ZERO_FLOATS, device=dev), 0]
     z[0].zero_()
     z[1] = 0
+    _GRAD[dev] = [torch.zeros(_GRAD_FLOATS, device=dev), 0]
+
+
+# Small gradients that are accumulated with atomics and RETURNED to autograd (conv biases, LayerNorm gamma/beta, time-bias
+# sums) are slices of one tensor that forward_train allocates zeroed — a fresh tensor per step, so a slice that lives on as
+# some parameter's .grad is never touched by a later step (unlike the scratch pool above, which is re-zeroed in place).
+_GRAD_FLOATS = 1 << 18
+_GRAD = {}             # device -> [tensor, offset]
+
+
+def _grad_zeros(n, dev):
+    """n zeroed floats for a returned gradient (second value True -> came from the step's tensor, already zero)"""
+    g = _GRAD.get(dev)
+    n_al = (n + 63) // 64 * 64
+    if g is None or g[1] + n_al > _GRAD_FLOATS:
+        return torch.zeros(n, device=dev), False
+    out = g[0][g[1]: g[1] + n]
+    g[1] += n_al
+    return out, True
 
 
 def _zeros(n, dev):
@@ -216,7 +235,7 @@ class ConvFn(torch.autograd.Function):
             dw = torch.empty_like(w)
             ws, pooled = _zeros(k * k * cout * cs, x.device)
             if want_db and pooled:                               # bias gradient as a by-product of the weight-gradient sweep
-                db = torch.zeros(cout, device=x.device)          # a returned gradient: never a slice of the per-step pool
+                db, _ = _grad_zeros(cout, x.device)              # a returned gradient: never a slice of the re-zeroed scratch pool
                 with _prezeroed(True):
                     N.check(_L().sbgm_conv2d_wgrad_bias(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), B, H, W,
                                                         cs, cin, cout, k, k, stride, pad, _st()))
@@ -230,8 +249,10 @@ class ConvFn(torch.autograd.Function):
             N.check(_L().sbgm_colsum(dy.data_ptr(), None, db.data_ptr(), dy.numel() // cout, cout, _st()))
         dtb = None
         if has_tb and ctx.needs_input_grad[4]:
-            dtb = torch.empty(B, cout, device=x.device)
-            N.check(_L().sbgm_samplesum(dy.data_ptr(), dtb.data_ptr(), B, dy.numel() // (B * cout), cout, _st()))
+            dtb, zeroed = _grad_zeros(B * cout, x.device)
+            dtb = dtb.view(B, cout)
+            with _prezeroed(zeroed):
+                N.check(_L().sbgm_samplesum(dy.data_ptr(), dtb.data_ptr(), B, dy.numel() // (B * cout), cout, _st()))
         return dx, dw, db, (dy if has_res and ctx.needs_input_grad[3] else None), dtb, None, None
 
 
@@ -274,8 +295,10 @@ class BNTrainFn(torch.autograd.Function):
                                             dx.data_ptr(), N.ptr(dres), dg.data_ptr(), db.data_ptr(), s12.data_ptr(), B, H * W, Cc, _st()))
         dtb = None
         if has_tb:
-            dtb = torch.empty(B, Cc, device=x.device)
-            N.check(_L().sbgm_samplesum(dy.data_ptr(), dtb.data_ptr(), B, H * W, Cc, _st()))
+            dtb, zeroed = _grad_zeros(B * Cc, x.device)
+            dtb = dtb.view(B, Cc)
+            with _prezeroed(zeroed):
+                N.check(_L().sbgm_samplesum(dy.data_ptr(), dtb.data_ptr(), B, H * W, Cc, _st()))
         return dx, dg, db, None, None, dres, dtb, None, None, None
 
 
@@ -329,10 +352,12 @@ class LayerNormFn(torch.autograd.Function):
         x, gamma = ctx.saved_tensors
         dy = dy.contiguous()
         M, Cc = x.shape
-        dx, dgb = torch.empty_like(x), torch.empty(2, Cc, device=x.device)
-        dg, db = dgb[0], dgb[1]                          # adjacent: the launcher zeroes both with one memset
-        N.check(_L().sbgm_layernorm_bwd(x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), M, Cc,
-                                        ctx.eps, _st()))
+        dx = torch.empty_like(x)
+        dgb, zeroed = _grad_zeros(2 * Cc, x.device)
+        dg, db = dgb[:Cc], dgb[Cc:]                      # adjacent: the launcher zeroes both with one memset (none if pooled)
+        with _prezeroed(zeroed):
+            N.check(_L().sbgm_layernorm_bwd(x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), M,
+                                            Cc, ctx.eps, _st()))
         return dx, dg, db, None
 
 

@@ -16,6 +16,7 @@ for r in win:
     agg[k][0] += 1
     agg[k][1] += (r["e"] - r["s"]) / 1e3
 tot = sum(v[1] for v in agg.values())
-print(f"window = 10 x {sys.argv[2]} ms: busy {tot / 10:.0f} us/step, {sum(v[0] for v in agg.values()) / 10:.0f} kernels/step")
+n = max([v[0] for k, v in agg.items() if "pack_conv_weights_batched" in k] + [1])      # launched once per step
+print(f"window of {n} steps: busy {tot / n:.0f} us/step, {sum(v[0] for v in agg.values()) / n:.0f} kernels/step")
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:50]:
-    print(f"{v[1] / 10:8.1f} us/step {v[0] / 10:6.1f} calls {v[1] / v[0]:7.1f} avg  {k}")
+    print(f"{v[1] / n:8.1f} us/step {v[0] / n:6.1f} calls {v[1] / v[0]:7.1f} avg  {k}")
