@@ -182,7 +182,8 @@ int sbgm_conv2d_fwd(const sbgm_conv_args* a, void* stream);
  * considered when a->ws is given.  Used by the training path, whose convolutions run op by op. */
 int sbgm_conv2d_tune(const sbgm_conv_args* a, int* tile, void* stream);
 /* Pack many convolution weights in one launch.  desc: DEVICE array of n descriptors; block_begin = exclusive prefix of
- * ceil(nsteps*Cout*16 / 256) over the descriptors, total_blocks = its total (nsteps from sbgm_conv_packed_numel / (Cout*16)).
+ * sbgm_conv_pack_weights_batched_blocks(Cout, KH, KW, cs) over the descriptors (the workgroups each weight needs),
+ * total_blocks = its total; nsteps = sbgm_conv_packed_numel / (Cout*16).
  * transposed != 0 packs the data-gradient operator: then Cout/Cin are the TRANSPOSED sizes (Cout = forward Cin, Cin = forward
  * Cout) and cs is the padded forward Cout, exactly as sbgm_conv_pack_weight_dgrad does for one weight. */
 typedef struct sbgm_pack_desc {
@@ -190,6 +191,7 @@ typedef struct sbgm_pack_desc {
     float* dst;            /* packed [nsteps][Cout][16] */
     int Cout, Cin, KH, KW, cs, nsteps, transposed, block_begin;
 } sbgm_pack_desc;
+int sbgm_conv_pack_weights_batched_blocks(int Cout, int KH, int KW, int c_pad);
 int sbgm_conv_pack_weights_batched(const sbgm_pack_desc* desc_dev, int n, int total_blocks, void* stream);
 /* Process-wide switch for the backward launchers (sbgm_conv2d_wgrad[_bias], sbgm_groupnorm_bwd, sbgm_batchnorm_bwd,
  * sbgm_layernorm_bwd's dgamma/dbeta, sbgm_samplesum's output, sbgm_batchnorm_train_fwd's sums): 1 = the caller

@@ -96,6 +96,7 @@ SIGNATURES = {
     "sbgm_conv2d_fwd": (_i, [C.POINTER(ConvArgs), _vp]),
     "sbgm_conv2d_tune": (_i, [C.POINTER(ConvArgs), C.POINTER(C.c_int), _vp]),
     "sbgm_conv_pack_weights_batched": (_i, [_vp, _i, _i, _vp]),
+    "sbgm_conv_pack_weights_batched_blocks": (_i, [_i, _i, _i, _i]),
     "sbgm_set_scratch_prezeroed": (_i, [_i]),
     "sbgm_conv_wino_packed_numel": (_i64, [_i, _i]),
     "sbgm_conv_wino_pack_weight": (_i, [_vp, _vp, _i, _i, _i, _vp]),

@@ -63,6 +63,7 @@ int sbgm_conv2d_fwd(const sbgm_conv_args* a, void* stream) {
     return sbgm_launch_conv(ConvGeom{a->KH, a->KW, a->stride, a->pad}, p, t, a->ws, ST);
 }
 
+int sbgm_conv_pack_weights_batched_blocks(int Cout, int KH, int KW, int c_pad) { return sbgm_conv_pack_blocks(Cout, KH, KW, c_pad); }
 int sbgm_conv_pack_weights_batched(const sbgm_pack_desc* desc_dev, int n, int total_blocks, void* stream) {
     return sbgm_launch_pack_conv_weights_batched(desc_dev, n, total_blocks, ST);
 }

@@ -41,6 +41,7 @@ struct ConvParams {
 };
 
 int sbgm_conv_nsteps(int KH, int KW, int cs);
+int sbgm_conv_pack_blocks(int Cout, int KH, int KW, int cs);   // workgroups one weight takes in the batched pack launch
 // transposed != 0 packs the data-gradient operator (swap Cout/Cin, flip taps); then Cout/Cin are the transposed sizes
 int sbgm_launch_pack_conv_weight(const float* w_oihw, float* wp, int Cout, int Cin, int KH, int KW, int cs, hipStream_t st,
                                  int transposed = 0);

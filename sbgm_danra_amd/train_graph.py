@@ -142,7 +142,7 @@ class _PackPlan:
             for dst, co_, ci_, cs_, tr in jobs:
                 nsteps = dst.numel() // (co_ * 16)
                 descs.append(N.PackDesc(ptr, dst.data_ptr(), co_, ci_, k, k, cs_, nsteps, tr, blk))
-                blk += (dst.numel() + 255) // 256
+                blk += _L().sbgm_conv_pack_weights_batched_blocks(co_, k, k, cs_)
         raw = (N.PackDesc * len(descs))(*descs)
         host = torch.frombuffer(bytearray(bytes(raw)), dtype=torch.uint8)
         self.desc, self.n, self.blocks = host.to(dev), len(descs), blk

@@ -384,3 +384,35 @@ def test_philox_normal_statistics_and_streams():
     c = torch.empty(n, device=DEV)
     N.check(lib().sbgm_randn_scaled(c.data_ptr(), 2.0, 1234, 0, n, N.stream()))
     assert torch.equal(c.cpu().double(), a)                               # counter-based: reproducible
+
+
+@pytest.mark.parametrize("transposed", [0, 1])
+def test_batched_weight_pack_equals_single_packs(transposed):
+    """sbgm_conv_pack_weights_batched (tiled through LDS for >= 16 channels) == one sbgm_conv_pack_weight[_dgrad] per weight"""
+    import ctypes
+    shapes = [(64, 64, 3), (128, 64, 3), (64, 48, 3), (256, 128, 1), (64, 5, 8), (64, 64, 8), (32, 16, 3), (48, 80, 3)]   # (Cout, Cin, k)
+    ws = [rnd(co, ci, k, k, seed=i).to(DEV) for i, (co, ci, k) in enumerate(shapes)]
+    descs, outs, blk = [], [], 0
+    for w, (co, ci, k) in zip(ws, shapes):
+        if transposed:
+            if ci % 16 or co % 16:
+                continue
+            pco, pci, cs = ci, co, co                       # operator sizes of the data gradient
+        else:
+            pco, pci, cs = co, ci, (2 if ci <= 2 else 4 if ci <= 4 else 8 if ci <= 8 else (ci + 15) // 16 * 16)
+        numel = lib().sbgm_conv_packed_numel(pco, k, k, cs)
+        single, batched = torch.empty(numel, device=DEV), torch.full((numel,), 7.0, device=DEV)
+        if transposed:
+            N.check(lib().sbgm_conv_pack_weight_dgrad(w.data_ptr(), single.data_ptr(), co, ci, k, k, N.stream()))
+        else:
+            N.check(lib().sbgm_conv_pack_weight(w.data_ptr(), single.data_ptr(), co, ci, k, k, cs, N.stream()))
+        descs.append(N.PackDesc(w.data_ptr(), batched.data_ptr(), pco, pci, k, k, cs, numel // (pco * 16), transposed, blk))
+        blk += lib().sbgm_conv_pack_weights_batched_blocks(pco, k, k, cs)
+        outs.append((single, batched))
+    raw = (N.PackDesc * len(descs))(*descs)
+    dev = torch.frombuffer(bytearray(bytes(raw)), dtype=torch.uint8).to(DEV)
+    N.check(lib().sbgm_conv_pack_weights_batched(dev.data_ptr(), len(descs), blk, N.stream()))
+    torch.cuda.synchronize()
+    assert len(outs) >= 4
+    for single, batched in outs:
+        assert torch.equal(single, batched)
