@@ -375,7 +375,7 @@ def main():
                 "whole_eval": {"ms": ms_eval, "gflop": flops_eval * 1e-9,
                                "fp32_frac": flops_eval / (ms_eval * 1e-3) / (PEAK_FP32_TFLOPS * 1e12),
                                "hbm_frac_layer_fused_bytes": BYTES_PER_EVAL(B, HW) / (ms_eval * 1e-3) / (PEAK_HBM_GBS * 1e9)}}
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:                   # the CPU reference leg is reported at N=1 only
             cpu = cpu_baseline(B, HW)
 
     if rank == 0:
