@@ -298,37 +298,50 @@ __global__ __launch_bounds__(WG_THREADS) void conv3x3_wgrad_lds_kernel(const flo
 }
 
 // =====================================================================================================================
-// Weight gradient of a 1x1 convolution (stride 1 or 2) and of nn.Linear over tokens: the split-K GEMM
-// dW[co][ci] = sum_m dy[m][co] * x[pixel(m)][ci], LDS-staged.  A workgroup of 8 waves owns one 64 x 64 block; per tile of
-// 128 output pixels it stages dy[128][64] and x[128][64] once, wave w takes pixels 16w..16w+15 (4 MFMA k-steps) and keeps
-// its own 64 x 64 partial block (16 accumulator quads: 8 LDS dword reads feed 16 MFMAs, 128 staged bytes per MFMA).  The 8
-// partial blocks fold through LDS; one atomic (or, without a pixel split, one plain OIHW store) per element and workgroup.
+// Weight gradient as one split-K GEMM per kernel tap, LDS-staged: dW[tap][co][ci] = sum_m dy[m][co] * x[pixel(m, tap)][ci].
+// Serves 1x1 convolutions and nn.Linear (one tap), and every other geometry the halo kernel above does not take (3x3
+// stride 2, 3x3 on 4x4 maps, the 8x8 stride-2 stem convolutions): a tap only shifts the input pixel, out-of-range pixels
+// load zeros.  A workgroup of 8 waves owns one (tap, 64 co, 64 ci) block; per tile of 128 output pixels it stages
+// dy[128][64] and x[128][64] once, wave w takes pixels 16w..16w+15 (4 MFMA k-steps) and keeps its own 64 x 64 partial
+// block (16 accumulator quads: 8 LDS dword reads feed 16 MFMAs, 128 staged bytes per MFMA).  The 8 partial blocks fold
+// through LDS; one atomic (or, without a pixel split, one plain OIHW store) per element and workgroup.
+// stem != 0 (padded Cin = 8, KW = 8): the 64 "channels" of a block are the (kw, ci) pairs of one kernel row kh, which are
+// 64 contiguous floats of the NHWC input row, and the slab is [kh][Cout][kw][8].
 // =====================================================================================================================
 constexpr int W1_PX = 128, W1_PS = 80;             // pixels per tile, LDS floats per pixel (64 channels + pad: conflict-free)
-__global__ __launch_bounds__(WG_THREADS) void conv1x1_wgrad_lds_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                                       float* __restrict__ dwp, float* __restrict__ dbias, int Mo,
-                                                                       int OH, int OW, int H, int W, int stride, int Cs, int Cout,
-                                                                       int tiles_per_wg, uint32_t dy_bytes, uint32_t x_bytes,
-                                                                       float* __restrict__ dw_direct, int Cin) {
+struct TapGeom {
+    int Mo, OH, OW, H, W, stride, pad, KW, taps, stem;
+};
+__global__ __launch_bounds__(WG_THREADS) void conv_tap_wgrad_lds_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                        float* __restrict__ dwp, float* __restrict__ dbias, TapGeom g,
+                                                                        int Cs, int Cout, int tiles_per_wg, uint32_t dy_bytes,
+                                                                        uint32_t x_bytes, float* __restrict__ dw_direct, int Cin) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* dys = reinterpret_cast<float*>(smem_raw);                   // [128 px][80]
     float* xs = dys + W1_PX * W1_PS;                                   // [128 px][80]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, kq = lane >> 4;
-    const int n_ci = Cs / 64;
-    const int co0 = (blockIdx.x / n_ci) * 64, ci0 = (blockIdx.x % n_ci) * 64;
-    const int n_tiles = (Mo + W1_PX - 1) / W1_PX;
+    const int n_ci = g.stem ? 1 : Cs / 64, n_co = Cout / 64;
+    int blk = blockIdx.x;
+    const int ci0 = (blk % n_ci) * 64; blk /= n_ci;
+    const int co0 = (blk % n_co) * 64;
+    const int tap = blk / n_co;
+    const int kh = g.stem ? tap : tap / g.KW, kw0 = g.stem ? 0 : tap - kh * g.KW;
+    const int slab_cs = g.stem ? 64 : Cs;                              // floats per (tap, co) row of the slab
+    dwp += (size_t)tap * Cout * slab_cs;
+    const int n_tiles = (g.Mo + W1_PX - 1) / W1_PX;
     const int t_begin = blockIdx.y * tiles_per_wg, t_end = min(n_tiles, t_begin + tiles_per_wg);
     const __amdgpu_buffer_rsrc_t dr = make_rsrc(dy, dy_bytes);
     const __amdgpu_buffer_rsrc_t xr = make_rsrc(x, x_bytes);
+    const bool shifted = g.stride != 1 || g.taps != 1 || g.pad != 0;
 
     f32x4 acc[4][4];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const bool do_bias = dbias != nullptr && ci0 == 0;
+    const bool do_bias = dbias != nullptr && ci0 == 0 && tap == 0;
     float bsum[4] = {0.f, 0.f, 0.f, 0.f};
 
     constexpr int QPT = W1_PX * 16 / WG_THREADS;                       // 4 quads of each operand per thread
@@ -338,15 +351,20 @@ __global__ __launch_bounds__(WG_THREADS) void conv1x1_wgrad_lds_kernel(const flo
         for (int u = 0; u < QPT; ++u) {
             const int q = tid + WG_THREADS * u;
             const int p = t * W1_PX + (q >> 4), c4 = (q & 15) * 4;
-            int ip = p;
-            if (stride != 1) {
-                const int b = p / (OH * OW), r = p - b * (OH * OW);
-                const int oy = r / OW, ox = r - oy * OW;
-                ip = (b * H + oy * stride) * W + ox * stride;
+            bool ok = p < g.Mo;
+            uint32_t xoff = (uint32_t)(p * Cs + ci0 + c4);
+            if (shifted) {
+                const int b = p / (g.OH * g.OW), r = p - b * (g.OH * g.OW);
+                const int oy = r / g.OW, ox = r - oy * g.OW;
+                const int iy = oy * g.stride - g.pad + kh;
+                const int ix = ox * g.stride - g.pad + (g.stem ? (c4 >> 3) : kw0);
+                xoff = (uint32_t)(((b * g.H + iy) * g.W + ix) * Cs + (g.stem ? (c4 & 7) : ci0 + c4));
+                rdy[u] = buf_load4(dr, ok ? (uint32_t)(p * Cout + co0 + c4) * 4u : 0x80000000u);
+                ok = ok & ((unsigned)iy < (unsigned)g.H) & ((unsigned)ix < (unsigned)g.W);
+            } else {
+                rdy[u] = buf_load4(dr, ok ? (uint32_t)(p * Cout + co0 + c4) * 4u : 0x80000000u);
             }
-            const bool ok = p < Mo;
-            rdy[u] = buf_load4(dr, ok ? (uint32_t)(p * Cout + co0 + c4) * 4u : 0x80000000u);
-            rx[u] = buf_load4(xr, ok ? (uint32_t)(ip * Cs + ci0 + c4) * 4u : 0x80000000u);
+            rx[u] = buf_load4(xr, ok ? xoff * 4u : 0x80000000u);
         }
     };
     auto tile_store = [&]() {
@@ -412,9 +430,21 @@ __global__ __launch_bounds__(WG_THREADS) void conv1x1_wgrad_lds_kernel(const flo
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int co = co0 + 16 * i + 4 * kq + e;
-            if (dw_direct) { if (ci < Cin) dw_direct[(size_t)co * Cin + ci] = o[e]; }
-            else atomicAdd(dwp + (size_t)co * Cs + ci, o[e]);
+            if (dw_direct) { if (ci < Cin) dw_direct[((size_t)co * Cin + ci) * g.taps + tap] = o[e]; }
+            else atomicAdd(dwp + (size_t)co * slab_cs + ci, o[e]);
         }
+    }
+}
+
+// stem slab [kh][Cout][kw][8] -> OIHW [Cout][Cin][KH][8]
+__global__ void unpack_wgrad_stem_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int Cout, int Cin, int KH) {
+    const size_t total = (size_t)Cout * Cin * KH * 8;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int kw = (int)(i & 7);
+        const int kh = (int)((i >> 3) % KH);
+        const int ci = (int)((i / ((size_t)8 * KH)) % Cin);
+        const int co = (int)(i / ((size_t)8 * KH * Cin));
+        dw[i] = dwp[(((size_t)kh * Cout + co) * 8 + kw) * 8 + ci];
     }
 }
 
@@ -1057,32 +1087,6 @@ int sbgm_launch_conv_wgrad(const float* dy, const float* x, float* dw_oihw, floa
     const size_t n = (size_t)KH * KW * Cout * Cs;
     if (!sbgm_scratch_prezeroed && dbias) SBGM_HIP(hipMemsetAsync(dbias, 0, (size_t)Cout * 4, st));
     const size_t dy_b = (size_t)M * Cout * 4, x_b = (size_t)B * H * W * Cs * 4;
-    if (KH == 1 && KW == 1 && PAD == 0 && (S == 1 || S == 2) && Cs % 64 == 0 && dy_b < (1ull << 31) && x_b < (1ull << 31) &&
-        getenv("SBGM_NO_LDS_WGRAD") == nullptr) {
-        const int blocks_x = (Cout / 64) * (Cs / 64);
-        const int n_tiles = (M + W1_PX - 1) / W1_PX;
-        const int wgs_y = std::max(1, std::min(n_tiles, (256 + blocks_x - 1) / blocks_x));      // one 8-wave workgroup per CU
-        const int tpw = (n_tiles + wgs_y - 1) / wgs_y;
-        const dim3 grid_lds(blocks_x, (n_tiles + tpw - 1) / tpw);
-        const size_t lds = (size_t)2 * W1_PX * W1_PS * 4;
-        static bool attr1_set = false;
-        if (!attr1_set) {
-            SBGM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv1x1_wgrad_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)lds));
-            attr1_set = true;
-        }
-        float* direct = grid_lds.y == 1 ? dw_oihw : nullptr;
-        if (!direct && !sbgm_scratch_prezeroed) SBGM_HIP(hipMemsetAsync(dwp_ws, 0, n * 4, st));
-        hipLaunchKernelGGL(conv1x1_wgrad_lds_kernel, grid_lds, dim3(WG_THREADS), lds, st, dy, x, dwp_ws, dbias, M, OH, OW, H, W, S, Cs, Cout,
-                           tpw, (uint32_t)dy_b, (uint32_t)x_b, direct, Cin);
-        SBGM_LAUNCH_CHECK();
-        if (!direct) {
-            hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(stream_blocks((size_t)Cout * Cin)), dim3(256), 0, st, dwp_ws, dw_oihw, Cout, Cin, Cs,
-                               1);
-            SBGM_LAUNCH_CHECK();
-        }
-        return 0;
-    }
     const bool lds16 = W % 16 == 0 && H % 16 == 0, lds8 = W == 8 && H == 8;
     if (KH == 3 && KW == 3 && S == 1 && PAD == 1 && Cs % 32 == 0 && (lds16 || lds8) && dy_b < (1ull << 31) && x_b < (1ull << 31) &&
         getenv("SBGM_NO_LDS_WGRAD") == nullptr) {
@@ -1111,6 +1115,39 @@ int sbgm_launch_conv_wgrad(const float* dy, const float* x, float* dw_oihw, floa
         if (!direct) {
             hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(stream_blocks((size_t)Cout * Cin * KH * KW)), dim3(256), 0, st, dwp_ws, dw_oihw,
                                Cout, Cin, Cs, KH * KW);
+            SBGM_LAUNCH_CHECK();
+        }
+        return 0;
+    }
+    const bool stem = Cs == 8 && KW == 8;
+    if ((Cs % 64 == 0 || stem) && dy_b < (1ull << 31) && x_b < (1ull << 31) && getenv("SBGM_NO_LDS_WGRAD") == nullptr) {
+        // one split-K GEMM per tap (1x1 / linear layers, and whatever the halo kernel above does not take)
+        const int taps = stem ? KH : KH * KW;
+        const int blocks_x = taps * (Cout / 64) * (stem ? 1 : Cs / 64);
+        const int n_tiles = (M + W1_PX - 1) / W1_PX;
+        const int wgs_y = std::max(1, std::min(n_tiles, (256 + blocks_x - 1) / blocks_x));      // one 8-wave workgroup per CU
+        const int tpw = (n_tiles + wgs_y - 1) / wgs_y;
+        const dim3 grid_lds(blocks_x, (n_tiles + tpw - 1) / tpw);
+        const size_t lds = (size_t)2 * W1_PX * W1_PS * 4;
+        static bool attr1_set = false;
+        if (!attr1_set) {
+            SBGM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tap_wgrad_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         (int)lds));
+            attr1_set = true;
+        }
+        float* direct = grid_lds.y == 1 && !stem ? dw_oihw : nullptr;
+        if (!direct && !sbgm_scratch_prezeroed) SBGM_HIP(hipMemsetAsync(dwp_ws, 0, n * 4, st));
+        const TapGeom tg{M, OH, OW, H, W, S, PAD, KW, KH * KW, stem ? 1 : 0};
+        hipLaunchKernelGGL(conv_tap_wgrad_lds_kernel, grid_lds, dim3(WG_THREADS), lds, st, dy, x, dwp_ws, dbias, tg, Cs, Cout, tpw,
+                           (uint32_t)dy_b, (uint32_t)x_b, direct, Cin);
+        SBGM_LAUNCH_CHECK();
+        if (stem) {
+            hipLaunchKernelGGL(unpack_wgrad_stem_kernel, dim3(stream_blocks((size_t)Cout * Cin * KH * KW)), dim3(256), 0, st, dwp_ws, dw_oihw,
+                               Cout, Cin, KH);
+            SBGM_LAUNCH_CHECK();
+        } else if (!direct) {
+            hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(stream_blocks((size_t)Cout * Cin * KH * KW)), dim3(256), 0, st, dwp_ws, dw_oihw, Cout,
+                               Cin, Cs, KH * KW);
             SBGM_LAUNCH_CHECK();
         }
         return 0;
