@@ -248,6 +248,22 @@ int sbgm_conv2d_wgrad(const float* dy, const float* x, float* dw_oihw, float* ws
 /* the same, plus the bias gradient db[Cout] = sum_p dy[p,:] produced by the waves that stream dy anyway */
 int sbgm_conv2d_wgrad_bias(const float* dy, const float* x, float* dw_oihw, float* dbias, float* ws, int B, int H, int W, int c_pad,
                            int Cin, int Cout, int KH, int KW, int stride, int pad, void* stream);
+/* `optimizer.step()` of torch.optim.Adam (decoupled = 0: weight decay as an L2 term on the gradient) or AdamW (decoupled = 1)
+ * over every parameter tensor in one launch (reference training.py:407, training_utils.py:50-59).  desc: DEVICE array of n
+ * descriptors, block_begin = exclusive prefix of sbgm_adam_step_blocks(numel), total_blocks = its total.  step: DEVICE
+ * scalar holding the step count t of THIS update (the caller increments it before the call), used for the bias corrections
+ * 1 - beta^t.  Update: m += (1-b1)(g'-m); v = b2 v + (1-b2) g'^2; p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps). */
+typedef struct sbgm_adam_desc {
+    float* p;              /* parameter */
+    const float* g;        /* gradient */
+    float* m;              /* exp_avg */
+    float* v;              /* exp_avg_sq */
+    int64_t numel;
+    int block_begin, reserved;
+} sbgm_adam_desc;
+int sbgm_adam_step_blocks(int64_t numel);
+int sbgm_adam_step_batched(const sbgm_adam_desc* desc_dev, int n, int total_blocks, const float* step, float lr, float beta1,
+                           float beta2, float eps, float weight_decay, int decoupled, void* stream);
 int sbgm_colsum(const float* x, const float* y /* NULL or multiplied elementwise */, float* out, int M, int C, void* stream);
 int sbgm_samplesum(const float* x, float* out /* [B,C] */, int B, int HW, int C, void* stream);
 /* ws: >= 8*B*C bytes */

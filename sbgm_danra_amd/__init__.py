@@ -2,6 +2,7 @@
 hot path behind the reference's Python surface.  Importing the package does not load the HIP
 library; the first kernel call does, and fails loudly if it is missing."""
 from . import _native  # noqa: F401
+from . import optim  # noqa: F401
 from .score_unet import (Decoder, DecoderBlock, Encoder, ImageSelfAttention, ScoreNet, SinusoidalEmbedding,  # noqa: F401
                          diffusion_coeff, diffusion_coeff_fn, loss_fn, marginal_prob_std, marginal_prob_std_fn)
 from .score_sampling import (Euler_Maruyama_sampler, edm_sigma_schedule, guided_score_fn, ode_sampler,  # noqa: F401

@@ -45,6 +45,10 @@ class PackDesc(C.Structure):
                 ("transposed", _i), ("block_begin", _i)]
 
 
+class AdamDesc(C.Structure):
+    _fields_ = [("p", _vp), ("g", _vp), ("m", _vp), ("v", _vp), ("numel", C.c_int64), ("block_begin", _i), ("reserved", _i)]
+
+
 class Profile(C.Structure):
     _fields_ = [("ms_total_with_events", _f), ("ms_conv", _f), ("ms_conv_max", _f), ("flops_conv", C.c_double),
                 ("flops_conv_max", C.c_double), ("n_conv", _i)]
@@ -97,6 +101,8 @@ SIGNATURES = {
     "sbgm_conv2d_tune": (_i, [C.POINTER(ConvArgs), C.POINTER(C.c_int), _vp]),
     "sbgm_conv_pack_weights_batched": (_i, [_vp, _i, _i, _vp]),
     "sbgm_conv_pack_weights_batched_blocks": (_i, [_i, _i, _i, _i]),
+    "sbgm_adam_step_blocks": (_i, [C.c_int64]),
+    "sbgm_adam_step_batched": (_i, [_vp, _i, _i, _vp, _f, _f, _f, _f, _f, _i, _vp]),
     "sbgm_set_scratch_prezeroed": (_i, [_i]),
     "sbgm_conv_wino_packed_numel": (_i64, [_i, _i]),
     "sbgm_conv_wino_pack_weight": (_i, [_vp, _vp, _i, _i, _i, _vp]),

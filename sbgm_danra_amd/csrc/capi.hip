@@ -67,6 +67,11 @@ int sbgm_conv_pack_weights_batched_blocks(int Cout, int KH, int KW, int c_pad) {
 int sbgm_conv_pack_weights_batched(const sbgm_pack_desc* desc_dev, int n, int total_blocks, void* stream) {
     return sbgm_launch_pack_conv_weights_batched(desc_dev, n, total_blocks, ST);
 }
+int sbgm_adam_step_blocks(int64_t numel) { return sbgm_adam_blocks(numel); }
+int sbgm_adam_step_batched(const sbgm_adam_desc* desc_dev, int n, int total_blocks, const float* step, float lr, float beta1,
+                           float beta2, float eps, float weight_decay, int decoupled, void* stream) {
+    return sbgm_launch_adam_batched(desc_dev, n, total_blocks, step, lr, beta1, beta2, eps, weight_decay, decoupled, ST);
+}
 int sbgm_set_scratch_prezeroed(int on) {
     const int prev = sbgm_scratch_prezeroed;
     sbgm_scratch_prezeroed = on ? 1 : 0;

@@ -12,9 +12,10 @@ import sys
 import time
 
 import torch.nn as nn
-from torch.optim import SGD, Adam, AdamW
+from torch.optim import SGD
 from torch.optim import lr_scheduler as _sched
 
+from .optim import Adam, AdamW            # torch's classes with a one-launch native step() for GPU parameters
 from .score_unet import Decoder, Encoder, ScoreNet, marginal_prob_std_fn
 from .synthetic_data import synthetic_loader
 from .utils import get_model_string
