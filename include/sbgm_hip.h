@@ -242,7 +242,8 @@ int sbgm_act_inplace(float* x, int64_t n, int act, void* stream);
  * (stride-2 layers with in_dil = 2 and an explicit output size).
  * ---------------------------------------------------------------------------------------------------------- */
 int sbgm_conv_pack_weight_dgrad(const float* w_oihw, float* packed, int Cout, int Cin, int KH, int KW, void* stream);
-/* dW (OIHW) = sum_p dy[p,:] (x) x[p@tap,:]; ws: >= KH*KW*Cout*c_pad floats */
+/* dW (OIHW) = sum_p dy[p,:] (x) x[p@tap,:]; ws: >= KH*KW*Cout*c_pad floats.  For a 1x1 kernel with c_pad == Cin (and c_pad % 64
+ * == 0) ws may be dw_oihw itself: the partial sums then meet directly in the gradient and the layout pass is skipped. */
 int sbgm_conv2d_wgrad(const float* dy, const float* x, float* dw_oihw, float* ws, int B, int H, int W, int c_pad, int Cin,
                       int Cout, int KH, int KW, int stride, int pad, void* stream);
 /* the same, plus the bias gradient db[Cout] = sum_p dy[p,:] produced by the waves that stream dy anyway */

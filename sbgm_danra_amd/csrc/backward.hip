@@ -1136,6 +1136,10 @@ int sbgm_launch_conv_wgrad(const float* dy, const float* x, float* dw_oihw, floa
             attr1_set = true;
         }
         float* direct = grid_lds.y == 1 && !stem ? dw_oihw : nullptr;
+        // ws == dw_oihw: for a 1x1 kernel without channel padding the slab IS the OIHW gradient, so the caller may hand in the
+        // (zeroed) gradient tensor as workspace and no unpack pass is needed
+        const bool aliased = dwp_ws == dw_oihw;
+        SBGM_CHECK(!aliased || (KH * KW == 1 && Cs == Cin), "wgrad: ws may alias dw only for 1x1 kernels with c_pad == Cin");
         if (!direct && !sbgm_scratch_prezeroed) SBGM_HIP(hipMemsetAsync(dwp_ws, 0, n * 4, st));
         const TapGeom tg{M, OH, OW, H, W, S, PAD, KW, KH * KW, stem ? 1 : 0};
         hipLaunchKernelGGL(conv_tap_wgrad_lds_kernel, grid_lds, dim3(WG_THREADS), lds, st, dy, x, dwp_ws, dbias, tg, Cs, Cout, tpw,
@@ -1145,7 +1149,7 @@ int sbgm_launch_conv_wgrad(const float* dy, const float* x, float* dw_oihw, floa
             hipLaunchKernelGGL(unpack_wgrad_stem_kernel, dim3(stream_blocks((size_t)Cout * Cin * KH * KW)), dim3(256), 0, st, dwp_ws, dw_oihw,
                                Cout, Cin, KH);
             SBGM_LAUNCH_CHECK();
-        } else if (!direct) {
+        } else if (!direct && !aliased) {
             hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(stream_blocks((size_t)Cout * Cin * KH * KW)), dim3(256), 0, st, dwp_ws, dw_oihw, Cout,
                                Cin, Cs, KH * KW);
             SBGM_LAUNCH_CHECK();

@@ -61,10 +61,10 @@ def _zero_reset(dev):
     _GRAD[dev] = [torch.zeros(_GRAD_FLOATS, device=dev), 0]
 
 
-# Small gradients that are accumulated with atomics and RETURNED to autograd (conv biases, LayerNorm gamma/beta, time-bias
-# sums) are slices of one tensor that forward_train allocates zeroed — a fresh tensor per step, so a slice that lives on as
+# Gradients that are accumulated with atomics and RETURNED to autograd (conv biases, LayerNorm gamma/beta, time-bias sums,
+# the weights of 1x1 convolutions / linears) are slices of one tensor that forward_train allocates zeroed — a fresh tensor per step, so a slice that lives on as
 # some parameter's .grad is never touched by a later step (unlike the scratch pool above, which is re-zeroed in place).
-_GRAD_FLOATS = 1 << 18
+_GRAD_FLOATS = 8 << 20
 _GRAD = {}             # device -> [tensor, offset]
 
 
@@ -232,8 +232,13 @@ class ConvFn(torch.autograd.Function):
             _conv_launch(dy, packed, dx, cout, cin, k, 1, k - 1 - pad, in_dil=2 if stride == 2 else 0, out_hw=(H, W))
         want_db = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(w)
-            ws, pooled = _zeros(k * k * cout * cs, x.device)
+            if k == 1 and cs == cin and cs % 64 == 0 and cout % 64 == 0:
+                # 1x1 / linear: the partial-sum slab has the OIHW layout, so the (zeroed) gradient itself is the workspace
+                ws, pooled = _grad_zeros(cout * cin, x.device)
+                dw = ws.view(cout, cin, 1, 1)
+            else:
+                dw = torch.empty_like(w)
+                ws, pooled = _zeros(k * k * cout * cs, x.device)
             if want_db and pooled:                               # bias gradient as a by-product of the weight-gradient sweep
                 db, _ = _grad_zeros(cout, x.device)              # a returned gradient: never a slice of the re-zeroed scratch pool
                 with _prezeroed(True):
