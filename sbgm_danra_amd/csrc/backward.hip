@@ -123,9 +123,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
 // whose K index is the pixel: 2 + 18 LDS dword reads feed 36 MFMAs per 4-pixel step.  The wave-level kernel above re-reads
 // dy 9x and x 9x from global memory and spends most of its time on per-pixel index arithmetic.
 // The 8 copies are folded through LDS tap by tap, so one workgroup sends 36 KB of fp32 atomics into the pre-zeroed
-// [tap][Cout][Cs] slab, from which unpack_wgrad_kernel writes OIHW.  That volume is what the epilogue costs (the atomic
-// units take ~1.5 TB/s whatever the address pattern): with 64 x 64 blocks split over 4 quarter-waves it was 4x larger and
-// cost more than the matrix work at training batch sizes.
+// [tap][Cout][Cs] slab, from which unpack_wgrad_kernel writes OIHW (a layer without a pixel split stores OIHW directly and
+// needs neither).  That volume is what the epilogue costs (the atomic units take ~1.5 TB/s for 64-byte runs and longer;
+// 4-byte scatter straight into OIHW costs twice as much): with 64 x 64 blocks split over 4 quarter-waves it was 4x larger
+// and cost more than the matrix work at training batch sizes.
 // Pixel stride in LDS = 48 floats: lanes (r16, kq) of a ds_read_b32 then fall on 64 distinct banks.
 // =====================================================================================================================
 constexpr int WG_PS = 48;                          // LDS floats per pixel
