@@ -36,6 +36,37 @@ FLOP_PER_SAMPLE_128 = 5.146e9     # SURVEY.md §8d, 128x128, C_in = 2
 BYTES_PER_EVAL = lambda b, hw: 76.2e6 + 29.2e6 * b * (hw / 128.0) ** 2   # noqa: E731  layer-fused model, SURVEY §8d
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a torchrun environment: start N rank processes (one per GPU, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* set as torch.distributed.run would) BEFORE this process touches the GPU, relay rank 0's JSON line and
+    exit with the worst child status.  The children are fresh interpreters started as child processes — nothing execs over a
+    process that has initialised the GPU."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out, _ = procs[0].communicate()
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    sys.stdout.write(out)
+    sys.stdout.flush()
+    return max(abs(rc) for rc in rcs)
+
+
+def git_head():
+    try:
+        import subprocess
+        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip()
+    except Exception:
+        return ""
+
+
 def build_model(dev, n_cond=1):
     import sbgm_danra_amd as S
     torch.manual_seed(42)
@@ -57,10 +88,9 @@ def cpu_baseline(batch, hw, budget_s=20.0):
     from oracle import torch_ref as O
     cores = os.cpu_count() or 1
     try:
-        cores = len(os.sched_getaffinity(0))
+        cores = len(os.sched_getaffinity(0))       # every core this process may run on (all cores, N stated)
     except Exception:
         pass
-    cores = min(cores, 16)             # the GPU box gives one GPU job a 16-core CPU share; more threads only thrash
     torch.set_num_threads(cores)
     torch.manual_seed(42)
     ora = O.build_scorenet(1).eval()
@@ -99,14 +129,19 @@ def train_bench(a):
     net = build_model(dev, n_cond=4)
     net.train()
     parallel.broadcast_parameters(net)
+    torch.manual_seed(1000 + rank)                 # identical weights, but every replica draws its own loss noise (t, z)
     # the reference's default foreach Adam issues ~330 tiny per-parameter kernels per step
     opt = S.optim.Adam(net.parameters(), lr=5e-4, weight_decay=1e-6)      # torch.optim.Adam with a one-launch native step()
-    bucket = parallel.GradientBucket(net.parameters()) if world > 1 else None
+    # the model's flat gradient arena IS the bucket: backward writes into it, one RCCL all-reduce, Adam reads it (no copies)
+    bucket = parallel.GradientBucket(net) if world > 1 else None
+    if a.sync_bn:
+        from sbgm_danra_amd.train_graph import set_sync_batchnorm
+        set_sync_batchnorm(True)
     B, HW = (a.batch if a.batch != 32 else 8), a.size
     g = torch.Generator().manual_seed(42 + rank)
     x, cond = torch.randn(B, 1, HW, HW, generator=g).to(dev), torch.randn(B, 4, HW, HW, generator=g).to(dev)
 
-    graphed = not a.no_graph
+    graphed = not a.no_graph and not (a.sync_bn and world > 1)     # SyncBatchNorm's collectives run eagerly inside the step
     def fwd_bwd():
         loss = S.loss_fn(net, x, S.marginal_prob_std_fn, cond_img=cond)
         loss.backward()
@@ -166,7 +201,8 @@ def train_bench(a):
                           "unit": "samples/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3,
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                           "config": {"workload": f"{HW}x{HW} 4-cond->1-target (C_in=5), batch {B}/GPU, loss_fn + backward + Adam"
-                                                 + (", RCCL gradient all-reduce (76 MB bucket)" if world > 1 else "")
+                                                 + (", RCCL gradient all-reduce (76 MB flat arena, no copies)" if world > 1 else "")
+                                                 + (", SyncBatchNorm" if (a.sync_bn and world > 1) else (", per-replica BatchNorm statistics" if world > 1 else ""))
                                                  + (", forward+backward replayed as one hipGraph" if graphed else ""),
                                      "global_batch": B * world, "final_loss": float(loss.detach())}}), flush=True)
     if world > 1:
@@ -232,10 +268,18 @@ def main():
     ap.add_argument("--tune-cache", default=None, help="tile-table file: loaded when present, else written after autotuning "
                                                        "(lets the rocprofv3 passes replay exactly the benchmarked kernels)")
     ap.add_argument("--profile-csv", default=None, help="write the per-convolution event timings here")
+    ap.add_argument("--sync-bn", action="store_true", help="train mode: SyncBatchNorm (statistics summed over the ranks), eager launches")
     ap.add_argument("--mode", choices=["sample", "train", "domain"], default="sample",
                     help="sample = BASELINE configs[1] (the headline metric); train = configs[2] optimizer steps; domain = "
                          "configs[4] full-domain tiled sampling (secondary lines)")
     a = ap.parse_args()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:      # plain `python bench.py --gpus N`: be our own launcher
+        sys.exit(spawn_ranks(a.gpus, sys.argv[1:]))
+    if os.environ.get("SBGM_BENCH_DRYRUN"):                # launcher self-test (tests/test_cpu_host.py): no GPU work
+        if int(os.environ.get("RANK", 0)) == 0:
+            print(json.dumps({"dryrun": True, "n_gpus": int(os.environ.get("WORLD_SIZE", 1)), "mode": a.mode,
+                              "master": os.environ.get("MASTER_ADDR", "") + ":" + os.environ.get("MASTER_PORT", "")}), flush=True)
+        return 0
     if a.mode == "train":
         return train_bench(a)
     if a.mode == "domain":
@@ -244,8 +288,8 @@ def main():
     rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
     local = int(os.environ.get("LOCAL_RANK", 0))
     if world != a.gpus:
-        if world == 1 and a.gpus > 1:
-            sys.exit("launch multi-GPU runs with torch.distributed.run --nproc-per-node N")
+        sys.exit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}, or without a "
+                 f"torchrun environment (bench.py then starts the ranks itself)")
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

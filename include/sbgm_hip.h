@@ -32,6 +32,9 @@ enum { SBGM_SAMPLER_EM = 0, SBGM_SAMPLER_PC = 1 };
  * (reference training_utils.py:645-666) + ScoreNet.forward (score_unet.py:829-879).
  * ---------------------------------------------------------------------------------------------------------- */
 typedef struct sbgm_model_config {
+    int struct_size;         /* = sizeof(sbgm_model_config) of the header the CALLER was compiled against; sbgm_model_create
+                                rejects any other value (a binding generated from an older header would otherwise be read past
+                                its end).  First member, so the check never reads beyond 4 bytes of a foreign struct. */
     int n_lsm_channels;      /* 0 or 2: lsm_cond value||mask          (cat order: x, lsm, topo, cond_img; :273-291) */
     int n_topo_channels;     /* 0 or 2 */
     int n_cond_channels;     /* LR condition channels */
@@ -48,7 +51,10 @@ typedef struct sbgm_model_config {
                                 ablation path (cfg.model.use_resize_conv = false, score_unet.py:470-475, :589) */
 } sbgm_model_config;
 
+/* Fails (non-zero, text in sbgm_last_error) when cfg->struct_size != sizeof(sbgm_model_config) of this library. */
 int sbgm_model_create(const sbgm_model_config* cfg, sbgm_model** out);
+/* sizeof(sbgm_model_config) as this library was compiled: lets a binding check its own struct before the first call. */
+int sbgm_model_config_size(void);
 void sbgm_model_destroy(sbgm_model* m);
 
 /* Number of state_dict entries the model expects, and the i-th entry's name / element count (host strings). */
@@ -103,7 +109,8 @@ typedef struct sbgm_sampler_args {
     float cfg_scale_corrector; /* w of the PC corrector evaluation (the reference clamps only this one to guidance_scale_max, :184-186) */
     /* Full-domain tiling (optional): the B samples are tiles of one domain.  tile_origins: device int32 [B][2] = (y0, x0),
      * x0 % 4 == 0; the in-kernel noise is then keyed by DOMAIN position, so overlapping tiles draw identical noise on the
-     * pixels they share.  NULL = independent samples. */
+     * pixels they share, and the Langevin step size of a tile uses that tile's own score norm (not the batch mean), so a tile's
+     * result does not depend on which tiles share its batch or its GPU.  NULL = independent samples. */
     const int* tile_origins;
     int domain_w;
 } sbgm_sampler_args;
@@ -222,6 +229,14 @@ int sbgm_layernorm_fwd(const float* x, float* y, const float* gamma, const float
 int sbgm_batchnorm_train_fwd(const float* x, float* y, const float* gamma, const float* beta, float* running_mean,
                              float* running_var, const float* residual, const float* tbias_after, int relu, int B, int HW,
                              int C, float eps, float momentum, void* stats_ws, float* mean_rstd_out, void* stream);
+/* SyncBatchNorm (new capability: the reference is single-device, so its BatchNorm sees the whole batch, score_unet.py:323; with
+ * the batch sharded over ranks the statistics must be summed over the ranks to reproduce that step).  The forward above in two
+ * halves: _stats leaves the per-channel fp64 sums (x, x^2) of the local batch in stats_ws[2*C]; the caller sums stats_ws over
+ * the ranks (one RCCL all-reduce of 2*C doubles); _apply finalises with n_total = sum over ranks of B*HW. */
+int sbgm_batchnorm_train_stats(const float* x, int B, int HW, int C, void* stats_ws, void* stream);
+int sbgm_batchnorm_train_apply(const float* x, float* y, const float* gamma, const float* beta, float* running_mean,
+                               float* running_var, const float* residual, const float* tbias_after, int relu, int B, int HW, int C,
+                               float eps, float momentum, void* stats_ws, double n_total, float* mean_rstd_out, void* stream);
 /* Core of nn.MultiheadAttention between in_proj and out_proj: qkv [B,S,3C] -> [B,S,C].  score_unet.py:142 */
 int sbgm_mha_core_fwd(const float* qkv, float* out, int B, int S, int C, int heads, void* stream);
 /* SinusoidalEmbedding (+ label embedding) -> SiLU -> Linear, for one projection.  score_unet.py:41-45, :377-381 */
@@ -274,6 +289,15 @@ int sbgm_groupnorm_bwd(const float* x, const float* dy, const float* gamma, cons
 int sbgm_batchnorm_bwd(const float* x, const float* dy, const float* y, const float* gamma, const float* tbias_after,
                        const float* mean_rstd /* [C,2] */, int relu, float* dx, float* dres, float* dgamma, float* dbeta,
                        float* ws, int B, int HW, int C, void* stream);
+/* SyncBatchNorm backward in two halves: _reduce leaves the local sums (g, g*xhat) per (sample, channel) in ws [B][C][2]; the caller
+ * sums them over samples and ranks into sync_sums [C][2] (one all-reduce of 2*C floats); _apply uses sync_sums / n_total for the two
+ * means (sync_sums NULL: the local ws and B*HW, i.e. exactly sbgm_batchnorm_bwd).  dgamma / dbeta stay LOCAL sums: they are
+ * averaged over the ranks with every other parameter gradient. */
+int sbgm_batchnorm_bwd_reduce(const float* x, const float* dy, const float* y, const float* tbias_after, const float* mean_rstd,
+                              int relu, float* ws, int B, int HW, int C, void* stream);
+int sbgm_batchnorm_bwd_apply(const float* x, const float* dy, const float* y, const float* gamma, const float* tbias_after,
+                             const float* mean_rstd, int relu, float* dx, float* dres, float* dgamma, float* dbeta, const float* ws,
+                             const float* sync_sums, double n_total, int B, int HW, int C, void* stream);
 int sbgm_layernorm_bwd(const float* x, const float* dy, const float* gamma, float* dx, float* dgamma, float* dbeta, int M,
                        int C, float eps, void* stream);
 int sbgm_mha_core_bwd(const float* qkv, const float* dout, float* dqkv, int B, int S, int C, int heads, void* stream);
@@ -285,6 +309,24 @@ int sbgm_time_proj_bwd(const float* dout, const float* weight, const float* semb
 int sbgm_label_emb_bwd(const float* demb, const int64_t* y, float* dtable, int B, int D, void* stream);
 int sbgm_act_fwd(const float* x, float* y, int64_t n, int act, void* stream);
 int sbgm_act_bwd(const float* x, const float* dy, float* dx, int64_t n, int act, void* stream);
+
+/* ---- the loss around the network: loss_fn (reference score_unet.py:936-985) --------------------------------------------
+ * perturb: t_b = U(0,1)*(1-t_eps)+t_eps, z ~ N(0,1), std_b = marginal_prob_std(t_b), x_perturbed = x + std_b*z  (:957-963).
+ *   z / t given (device tensors [B,1,H,W] / [B]): used verbatim (parity runs inject the reference's draws; z_out is then not
+ *   written and may be NULL).  Either NULL: drawn in the kernel with Philox keyed by `seed` (rng_state NULL; eager calls pass a
+ *   fresh seed per call) or by rng_state = device uint64[2] {seed, offset}; sbgm_dsm_loss_fwd advances that offset by one, so a
+ *   captured (hipGraph) step replays with fresh noise.
+ * loss_fwd: loss[0] = mean_b sum_{chw} w*(score*std_b + z)^2, w = sigmoid(sdf)*0.5+0.5 or 1 (sdf NULL)           (:974-984);
+ *   partial_ws: >= 8 * B * sbgm_dsm_loss_blocks(per_sample) bytes (one fp64 partial per workgroup, summed in fixed order).
+ * loss_bwd: dscore = dloss[0] * (2/B) * w * (score*std_b + z) * std_b   (dloss: DEVICE scalar, autograd's grad_output). */
+int sbgm_dsm_loss_blocks(int64_t per_sample);
+int sbgm_dsm_perturb(const float* x, const float* z, const float* t, const uint64_t* rng_state, uint64_t seed, float t_eps, float sigma,
+                     float* x_perturbed, float* z_out, float* t_out /* [B] */, float* std_out /* [B] */, int B,
+                     int64_t per_sample, void* stream);
+int sbgm_dsm_loss_fwd(const float* score, const float* z, const float* std, const float* sdf, void* partial_ws, float* loss,
+                      uint64_t* rng_state /* advanced; may be NULL */, int B, int64_t per_sample, void* stream);
+int sbgm_dsm_loss_bwd(const float* score, const float* z, const float* std, const float* sdf, const float* dloss, float* dscore,
+                      int B, int64_t per_sample, void* stream);
 
 /* Sampler updates with explicit scalars (the fused loop above uses a device-side table instead).
  * z NULL -> Philox draw keyed by (seed, draw_index).

@@ -228,6 +228,44 @@ noise = [torch.randn(2, 1, 32, 32) for _ in range(4)]
 np.savez_compressed(os.path.join(GOLD, "em_cfg_b2_32_3steps.npz"),
                     **npz({**{k: inp[k] for k in ("y", "cond_img", "lsm_cond", "topo_cond")}, "noise": torch.stack(noise), "mean_x": xr}))
 
+# ---- ode_sampler (score_sampling.py:239-300): scipy RK45 over the flattened state, unconditional 1-channel model, injected start z
+ref0, ora0, sd0 = pair(0, None)
+ref0.eval(), ora0.eval()
+gz = torch.Generator().manual_seed(123)
+z_ode = torch.randn(2, 1, 32, 32, generator=gz) * R.marginal_prob_std_fn(torch.ones(2))[:, None, None, None]
+ode_out = {"z": z_ode}
+for tol, tag in ((1e-5, "tol1e-5"), (1e-3, "tol1e-3")):
+    xr = RS.ode_sampler(ref0, R.marginal_prob_std_fn, R.diffusion_coeff_fn, batch_size=2, device="cpu", z=z_ode, atol=tol, rtol=tol)
+    xo, nfev = O.ode_sampler(ora0, O.marginal_prob_std_fn, O.diffusion_coeff_fn, batch_size=2, device="cpu", z=z_ode, atol=tol, rtol=tol,
+                             return_nfev=True)
+    report[f"ode_sampler/{tag}"] = maxrel(xo, xr)
+    assert torch.equal(xo, xr) and xr.dtype == torch.float64, tag
+    ode_out[f"x_{tag}"] = xr
+    ode_out[f"nfev_{tag}"] = np.int64(nfev)
+np.savez_compressed(os.path.join(GOLD, "ode_b2_32.npz"), **npz(ode_out))
+
+# ---- literal launch_generation behaviour (evaluate_sbgm/generation.py:47 never calls .eval()): PC sampling with BatchNorm in
+# TRAIN mode at a batch large enough for well-conditioned batch statistics (B = 4 at 64x64: >= 16 values per channel) ----------
+ref, ora, sd = pair(1, None)
+for m in (ref, ora):
+    m.load_state_dict(sd)
+    m.train()
+cond4 = inputs(64, 4, 64, 1, False, 0)["cond_img"]
+torch.manual_seed(17)
+xr = RS.pc_sampler(ref, R.marginal_prob_std_fn, R.diffusion_coeff_fn, batch_size=4, num_steps=2, device="cpu", img_size=64, cond_img=cond4)
+torch.manual_seed(17)
+xo = O.pc_sampler(ora, O.marginal_prob_std_fn, O.diffusion_coeff_fn, batch_size=4, num_steps=2, device="cpu", img_size=64, cond_img=cond4)
+report["pc_sampler_train_bn"] = maxrel(xo, xr)
+assert report["pc_sampler_train_bn"] <= 1e-6
+torch.manual_seed(17)
+noise = [torch.randn(4, 1, 64, 64) for _ in range(5)]
+rs = ref.state_dict()
+np.savez_compressed(os.path.join(GOLD, "pc_trainbn_b4_64_2steps.npz"),
+                    **npz(dict(cond_img=cond4, noise=torch.stack(noise), x_mean=xr,
+                               bn1_running_mean=rs["encoder.bn1.running_mean"], bn1_running_var=rs["encoder.bn1.running_var"],
+                               l4_running_var=rs["encoder.layer4.1.bn2.running_var"],
+                               num_batches_tracked=rs["encoder.bn1.num_batches_tracked"])))
+
 # ---- ConvTranspose2d decoder (model.use_resize_conv = false, score_unet.py:470-475): forward, loss and two gradients -------
 ref, ora, sd = pair(1, None, resize=False)
 tinp = inputs(4242, 2, 64, 1, False, 0)

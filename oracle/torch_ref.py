@@ -370,6 +370,35 @@ def pc_sampler(score_model, marginal_prob_std, diffusion_coeff, batch_size=64, n
     return x_mean
 
 
+def ode_sampler(score_model, marginal_prob_std, diffusion_coeff, num_steps=100, batch_size=64, atol=1e-5, rtol=1e-5,
+                device="cpu", z=None, eps=1e-3, img_size=64, y=None, cond_img=None, lsm_cond=None, topo_cond=None,
+                cfg=None, return_nfev=False):
+    """Probability-flow ODE with scipy's RK45 — score_sampling.py:239-300.  Like the reference it starts from
+    32x32 unless `z` is given (:279-283), evaluates the network on (x, t) ONLY (no conditioning reaches it,
+    :290), builds t as float64 ones * t cast to fp32 (:287-288), and squares g(t) = sigma^t in fp32 before the
+    float64 product with the score (:296-297).  `return_nfev` (not in the reference, which only logs it)."""
+    from scipy import integrate
+    t = torch.ones(batch_size, device=device)
+    init_x = torch.randn(batch_size, 1, 32, 32, device=device) * marginal_prob_std(t)[:, None, None, None] if z is None else z
+    shape = init_x.shape
+
+    def score_eval_wrapper(sample, time_steps):
+        sample = torch.tensor(sample, device=device, dtype=torch.float32).reshape(shape)
+        time_steps = torch.tensor(time_steps, device=device, dtype=torch.float32).reshape((sample.shape[0],))
+        with torch.no_grad():
+            score = score_model(sample, time_steps)
+        return score.cpu().numpy().reshape((-1,)).astype(np.float64)
+
+    def ode_func(tt, x):
+        time_steps = np.ones((shape[0],)) * tt
+        g = diffusion_coeff(torch.tensor(tt)).cpu().numpy()
+        return -0.5 * (g ** 2) * score_eval_wrapper(x, time_steps)
+
+    res = integrate.solve_ivp(ode_func, (1.0, eps), init_x.reshape(-1).cpu().numpy(), rtol=rtol, atol=atol, method="RK45")
+    x = torch.tensor(res.y[:, -1], device=device).reshape(shape)
+    return (x, res.nfev) if return_nfev else x
+
+
 # ----------------------------------------------------------------------------------------------
 # Deterministic, framework-independent weight generator (SURVEY.md §8c item 1): a counter-based hash of
 # (tensor name, flat index) -> uniform value, so the 76 MB state_dict never has to be committed.

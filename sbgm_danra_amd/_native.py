@@ -22,7 +22,7 @@ _vp, _i, _f, _i64, _u64 = C.c_void_p, C.c_int, C.c_float, C.c_int64, C.c_uint64
 
 
 class ModelConfig(C.Structure):
-    _fields_ = [("n_lsm_channels", _i), ("n_topo_channels", _i), ("n_cond_channels", _i), ("time_embedding", _i),
+    _fields_ = [("struct_size", _i), ("n_lsm_channels", _i), ("n_topo_channels", _i), ("n_cond_channels", _i), ("time_embedding", _i),
                 ("block_layers", _i * 4), ("n_heads", _i), ("num_classes", _i), ("last_fmap_channels", _i),
                 ("decoder_norm", _i), ("gn_groups", _i), ("decoder_activation", _i), ("sigma", _f), ("decoder_transpose", _i)]
 
@@ -67,6 +67,7 @@ SIGNATURES = {
     "sbgm_last_error": (C.c_char_p, []),
     "sbgm_abi_version": (_i, []),
     "sbgm_model_create": (_i, [C.POINTER(ModelConfig), C.POINTER(_vp)]),
+    "sbgm_model_config_size": (_i, []),
     "sbgm_model_destroy": (None, [_vp]),
     "sbgm_model_num_params": (_i, [_vp]),
     "sbgm_model_param_name": (C.c_char_p, [_vp, _i]),
@@ -110,6 +111,10 @@ SIGNATURES = {
     "sbgm_groupnorm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
     "sbgm_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "sbgm_batchnorm_train_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
+    "sbgm_batchnorm_train_stats": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "sbgm_batchnorm_train_apply": (_i, [_vp] * 8 + [_i, _i, _i, _i, _f, _f, _vp, C.c_double, _vp, _vp]),
+    "sbgm_batchnorm_bwd_reduce": (_i, [_vp] * 5 + [_i, _vp, _i, _i, _i, _vp]),
+    "sbgm_batchnorm_bwd_apply": (_i, [_vp] * 6 + [_i] + [_vp] * 6 + [C.c_double, _i, _i, _i, _vp]),
     "sbgm_mha_core_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "sbgm_time_proj_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "sbgm_cout1_pack_weight": (_i, [_vp, _vp, _i, _vp]),
@@ -130,11 +135,17 @@ SIGNATURES = {
     "sbgm_label_emb_bwd": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "sbgm_act_fwd": (_i, [_vp, _vp, _i64, _i, _vp]),
     "sbgm_act_bwd": (_i, [_vp, _vp, _vp, _i64, _i, _vp]),
+    "sbgm_dsm_loss_blocks": (_i, [_i64]),
+    "sbgm_dsm_perturb": (_i, [_vp, _vp, _vp, _vp, _u64, _f, _f, _vp, _vp, _vp, _vp, _i, _i64, _vp]),
+    "sbgm_dsm_loss_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _vp]),
+    "sbgm_dsm_loss_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i64, _vp]),
     "sbgm_em_step": (_i, [_vp, _vp, _vp, _vp, _f, _f, _f, _u64, _u64, _i64, _vp]),
     "sbgm_langevin_step": (_i, [_vp, _vp, _vp, _f, _vp, _u64, _u64, _i, _i64, _vp]),
     "sbgm_cfg_combine": (_i, [_vp, _vp, _vp, _f, _i64, _vp]),
     "sbgm_randn_scaled": (_i, [_vp, _f, _u64, _u64, _i64, _vp]),
 }
+
+ABI_VERSION = 2          # include/sbgm_hip.h: sbgm_abi_version()
 
 _lib = None
 
@@ -155,8 +166,27 @@ def lib() -> C.CDLL:
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(l, name)          # AttributeError here = header/library mismatch
             fn.restype, fn.argtypes = res, args
+        if l.sbgm_abi_version() != ABI_VERSION or l.sbgm_model_config_size() != C.sizeof(ModelConfig):
+            raise NativeError(f"{LIB_PATH} has ABI version {l.sbgm_abi_version()} / a {l.sbgm_model_config_size()}-byte model config; this "
+                              f"binding expects version {ABI_VERSION} / {C.sizeof(ModelConfig)} bytes: rebuild the library")
         _lib = l
     return _lib
+
+
+# Weights can change without torch noticing: the native Adam step writes parameters through raw pointers and a replayed
+# hipGraph re-runs captured BatchNorm running-statistics updates, neither of which bumps a tensor's version counter.  Every such
+# writer calls bump_generation(); ScoreNet's engine compares generation() (with the version counters) before reusing its
+# uploaded copy of the weights.
+_generation = 0
+
+
+def bump_generation() -> None:
+    global _generation
+    _generation += 1
+
+
+def generation() -> int:
+    return _generation
 
 
 def check(rc: int) -> None:

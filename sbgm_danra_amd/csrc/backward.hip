@@ -494,6 +494,8 @@ struct NormBwdArgs {
     float* dgamma;         // [C] or null  (parameter gradients: written by block (0,0) of the apply pass from s12)
     float* dbeta;          // [C] or null
     float* dtbias;         // [B][C] or null (GroupNorm: the time bias sits inside the activation)
+    const float* sync_sums;// BatchNorm only, or null: [C][2] sums of (g, g*xhat) over ALL ranks (SyncBatchNorm); the means then
+    float n_total;         // use these and n_total instead of the local s12 and B*HW (dgamma/dbeta stay local sums)
 };
 
 __device__ __forceinline__ float act_grad(float u, int act) {
@@ -570,10 +572,11 @@ __global__ __launch_bounds__(256) void norm_bwd_apply_kernel(NormBwdArgs a) {
     const int b = blockIdx.y;
     const int cq = a.C >> 2, cpg = a.C / a.G;
     if (BATCHNORM) {
-        const float inv_n = 1.f / ((float)a.B * a.HW);
+        const float inv_n = a.sync_sums ? 1.f / a.n_total : 1.f / ((float)a.B * a.HW);
         for (int c = threadIdx.x; c < a.C; c += blockDim.x) {
             float t1 = 0.f, t2 = 0.f;
-            for (int bb = 0; bb < a.B; ++bb) { t1 += a.s12[((size_t)bb * a.C + c) * 2]; t2 += a.s12[((size_t)bb * a.C + c) * 2 + 1]; }
+            if (a.sync_sums) { t1 = a.sync_sums[2 * c]; t2 = a.sync_sums[2 * c + 1]; }
+            else for (int bb = 0; bb < a.B; ++bb) { t1 += a.s12[((size_t)bb * a.C + c) * 2]; t2 += a.s12[((size_t)bb * a.C + c) * 2 + 1]; }
             m12[2 * c] = t1 * inv_n;                         // gamma factors out per channel for BatchNorm
             m12[2 * c + 1] = t2 * inv_n;
         }
@@ -1187,12 +1190,9 @@ int sbgm_launch_samplesum(const float* x, float* out, int B, int HW, int C, hipS
     return 0;
 }
 
-static int norm_bwd(bool bn, NormBwdArgs a, float* dgamma, float* dbeta, float* dtbias, hipStream_t st) {
+static int norm_bwd_reduce(bool bn, const NormBwdArgs& a, hipStream_t st) {
     SBGM_CHECK(a.C % 4 == 0 && a.C <= 1024, "norm_bwd: C=%d unsupported", a.C);
     if (!sbgm_scratch_prezeroed) SBGM_HIP(hipMemsetAsync(a.s12, 0, (size_t)a.B * a.C * 2 * 4, st));
-    a.dgamma = dgamma;
-    a.dbeta = dbeta;
-    a.dtbias = dtbias;
     const int lanes_px = std::max(1, 256 / (a.C / 4));
     int chunks = std::max(1, std::min(256, a.HW / (lanes_px * 4)));      // measured: 4 px per thread; 16 was 7 % slower per step
     const int ppb = (a.HW + chunks - 1) / chunks;
@@ -1200,12 +1200,43 @@ static int norm_bwd(bool bn, NormBwdArgs a, float* dgamma, float* dbeta, float* 
     if (bn) hipLaunchKernelGGL(norm_bwd_reduce_kernel<true>, dim3(chunks, a.B), dim3(256), 0, st, a, ppb);
     else hipLaunchKernelGGL(norm_bwd_reduce_kernel<false>, dim3(chunks, a.B), dim3(256), 0, st, a, ppb);
     SBGM_LAUNCH_CHECK();
+    return 0;
+}
+
+static int norm_bwd_apply(bool bn, const NormBwdArgs& a, hipStream_t st) {
+    SBGM_CHECK(a.C % 4 == 0 && a.C <= 1024, "norm_bwd: C=%d unsupported", a.C);
     const size_t per_sample = (size_t)a.HW * (a.C / 4);
     const int bx = (int)std::max<size_t>(1, std::min<size_t>((per_sample + 255) / 256, 2048 / std::max(1, a.B) + 1));
     if (bn) hipLaunchKernelGGL(norm_bwd_apply_kernel<true>, dim3(bx, a.B), dim3(256), 2 * a.C * 4, st, a);
     else hipLaunchKernelGGL(norm_bwd_apply_kernel<false>, dim3(bx, a.B), dim3(256), 2 * a.C * 4, st, a);
     SBGM_LAUNCH_CHECK();
     return 0;
+}
+
+static int norm_bwd(bool bn, NormBwdArgs a, float* dgamma, float* dbeta, float* dtbias, hipStream_t st) {
+    a.dgamma = dgamma;
+    a.dbeta = dbeta;
+    a.dtbias = dtbias;
+    if (norm_bwd_reduce(bn, a, st)) return 1;
+    return norm_bwd_apply(bn, a, st);
+}
+
+// SyncBatchNorm backward in two calls: the caller all-reduces the per-channel sums of s12 between them
+int sbgm_launch_batchnorm_bwd_reduce(const float* x, const float* dy, const float* y, const float* tbias_after, const float* mr,
+                                     int relu, float* s12_ws, int B, int HW, int C, hipStream_t st) {
+    NormBwdArgs a{x, dy, y, nullptr, nullptr, nullptr, tbias_after, mr, nullptr, nullptr, s12_ws, B, HW, C, 1, SBGM_ACT_NONE, relu, 0};
+    return norm_bwd_reduce(true, a, st);
+}
+int sbgm_launch_batchnorm_bwd_apply(const float* x, const float* dy, const float* y, const float* gamma, const float* tbias_after,
+                                    const float* mr, int relu, float* dx, float* dres, float* dgamma, float* dbeta, const float* s12_ws,
+                                    const float* sync_sums, double n_total, int B, int HW, int C, hipStream_t st) {
+    NormBwdArgs a{x, dy, y, gamma, nullptr, nullptr, tbias_after, mr, dx, dres, const_cast<float*>(s12_ws), B, HW, C, 1, SBGM_ACT_NONE,
+                  relu, dres != nullptr};
+    a.dgamma = dgamma;
+    a.dbeta = dbeta;
+    a.sync_sums = sync_sums;
+    a.n_total = (float)n_total;
+    return norm_bwd_apply(true, a, st);
 }
 
 int sbgm_launch_groupnorm_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* skip,

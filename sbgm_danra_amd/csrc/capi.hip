@@ -72,6 +72,41 @@ int sbgm_adam_step_batched(const sbgm_adam_desc* desc_dev, int n, int total_bloc
                            float beta2, float eps, float weight_decay, int decoupled, void* stream) {
     return sbgm_launch_adam_batched(desc_dev, n, total_blocks, step, lr, beta1, beta2, eps, weight_decay, decoupled, ST);
 }
+int sbgm_batchnorm_train_stats(const float* x, int B, int HW, int C, void* stats_ws, void* stream) {
+    return sbgm_launch_batchnorm_stats(x, B, HW, C, static_cast<double*>(stats_ws), ST);
+}
+int sbgm_batchnorm_train_apply(const float* x, float* y, const float* gamma, const float* beta, float* running_mean,
+                               float* running_var, const float* residual, const float* tbias_after, int relu, int B, int HW, int C,
+                               float eps, float momentum, void* stats_ws, double n_total, float* mean_rstd_out, void* stream) {
+    return sbgm_launch_batchnorm_apply(x, y, gamma, beta, running_mean, running_var, residual, tbias_after, relu, B, HW, C, eps, momentum,
+                                       static_cast<double*>(stats_ws), n_total, ST, mean_rstd_out);
+}
+int sbgm_batchnorm_bwd_reduce(const float* x, const float* dy, const float* y, const float* tbias_after, const float* mean_rstd,
+                              int relu, float* ws, int B, int HW, int C, void* stream) {
+    return sbgm_launch_batchnorm_bwd_reduce(x, dy, y, tbias_after, mean_rstd, relu, ws, B, HW, C, ST);
+}
+int sbgm_batchnorm_bwd_apply(const float* x, const float* dy, const float* y, const float* gamma, const float* tbias_after,
+                             const float* mean_rstd, int relu, float* dx, float* dres, float* dgamma, float* dbeta, const float* ws,
+                             const float* sync_sums, double n_total, int B, int HW, int C, void* stream) {
+    return sbgm_launch_batchnorm_bwd_apply(x, dy, y, gamma, tbias_after, mean_rstd, relu, dx, dres, dgamma, dbeta, ws, sync_sums, n_total,
+                                           B, HW, C, ST);
+}
+int sbgm_dsm_loss_blocks(int64_t per_sample) { return sbgm_dsm_nblk(per_sample); }
+int sbgm_dsm_perturb(const float* x, const float* z, const float* t, const uint64_t* rng_state, uint64_t seed, float t_eps, float sigma,
+                     float* x_perturbed, float* z_out, float* t_out, float* std_out, int B, int64_t per_sample, void* stream) {
+    return sbgm_launch_dsm_perturb(x, z, t, reinterpret_cast<const unsigned long long*>(rng_state), (unsigned long long)seed, t_eps, sigma,
+                                   x_perturbed, z_out,
+                                   t_out, std_out, B, (size_t)per_sample, ST);
+}
+int sbgm_dsm_loss_fwd(const float* score, const float* z, const float* std, const float* sdf, void* partial_ws, float* loss,
+                      uint64_t* rng_state, int B, int64_t per_sample, void* stream) {
+    return sbgm_launch_dsm_loss_fwd(score, z, std, sdf, static_cast<double*>(partial_ws), loss,
+                                    reinterpret_cast<unsigned long long*>(rng_state), B, (size_t)per_sample, ST);
+}
+int sbgm_dsm_loss_bwd(const float* score, const float* z, const float* std, const float* sdf, const float* dloss, float* dscore,
+                      int B, int64_t per_sample, void* stream) {
+    return sbgm_launch_dsm_loss_bwd(score, z, std, sdf, dloss, dscore, B, (size_t)per_sample, ST);
+}
 int sbgm_set_scratch_prezeroed(int on) {
     const int prev = sbgm_scratch_prezeroed;
     sbgm_scratch_prezeroed = on ? 1 : 0;

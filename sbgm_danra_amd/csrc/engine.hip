@@ -914,10 +914,14 @@ const char* sbgm_get_error();
 extern "C" {
 
 const char* sbgm_last_error(void) { return sbgm_get_error(); }
-int sbgm_abi_version(void) { return 1; }
+int sbgm_abi_version(void) { return 2; }
+int sbgm_model_config_size(void) { return (int)sizeof(sbgm_model_config); }
 
 int sbgm_model_create(const sbgm_model_config* cfg, sbgm_model** out) {
     SBGM_CHECK(cfg && out, "model_create: null argument");
+    SBGM_CHECK(cfg->struct_size == (int)sizeof(sbgm_model_config),
+               "model_create: sbgm_model_config.struct_size = %d but this library's struct has %d bytes (ABI version %d): the caller "
+               "was built against a different include/sbgm_hip.h", cfg->struct_size, (int)sizeof(sbgm_model_config), sbgm_abi_version());
     std::unique_ptr<sbgm_model> m(new sbgm_model());
     if (m->build(*cfg)) return 1;
     *out = m.release();

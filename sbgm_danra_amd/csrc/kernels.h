@@ -130,6 +130,17 @@ int sbgm_launch_batchnorm_train(const float* x, float* y, const float* gamma, co
                                 int HW, int C, float eps, float momentum, double* stats_ws, hipStream_t st,
                                 float* mr_out = nullptr);
 
+// SyncBatchNorm halves (the caller all-reduces stats_ws / the s12 channel sums over the ranks in between)
+int sbgm_launch_batchnorm_stats(const float* x, int B, int HW, int C, double* stats_ws, hipStream_t st);
+int sbgm_launch_batchnorm_apply(const float* x, float* y, const float* gamma, const float* beta, float* running_mean,
+                                float* running_var, const float* res, const float* tbias_after, int relu, int B, int HW, int C,
+                                float eps, float momentum, double* stats_ws, double n_total, hipStream_t st, float* mr_out = nullptr);
+int sbgm_launch_batchnorm_bwd_reduce(const float* x, const float* dy, const float* y, const float* tbias_after, const float* mr,
+                                     int relu, float* s12_ws, int B, int HW, int C, hipStream_t st);
+int sbgm_launch_batchnorm_bwd_apply(const float* x, const float* dy, const float* y, const float* gamma, const float* tbias_after,
+                                    const float* mr, int relu, float* dx, float* dres, float* dgamma, float* dbeta, const float* s12_ws,
+                                    const float* sync_sums, double n_total, int B, int HW, int C, hipStream_t st);
+
 // ---- attention.hip -------------------------------------------------------------------------------------
 int sbgm_launch_mha_core(const float* qkv, float* out, int B, int S, int C, int heads, hipStream_t st);
 
@@ -165,6 +176,15 @@ int sbgm_launch_langevin(float* x, const float* score, const float* z, float snr
                          SamplerState* state, unsigned long long draw_index, unsigned long long seed, int B,
                          size_t per_sample, hipStream_t st, NoiseMap nm = NoiseMap{});
 int sbgm_launch_cfg_combine(float* out, const float* s_cond, const float* s_uncond, float scale, size_t n, hipStream_t st);
+
+// ---- dsm_loss.hip (the loss around the network) -----------------------------------------------------------------------
+int sbgm_dsm_nblk(int64_t per_sample);
+int sbgm_launch_dsm_perturb(const float* x, const float* z_in, const float* t_in, const unsigned long long* rng,
+                            unsigned long long seed, float t_eps, float sigma, float* xp, float* z_out, float* t_out, float* std_out, int B, size_t per, hipStream_t st);
+int sbgm_launch_dsm_loss_fwd(const float* score, const float* z, const float* std, const float* sdf, double* partial_ws, float* loss,
+                             unsigned long long* rng_advance, int B, size_t per, hipStream_t st);
+int sbgm_launch_dsm_loss_bwd(const float* score, const float* z, const float* std, const float* sdf, const float* dloss, float* dscore,
+                             int B, size_t per, hipStream_t st);
 
 // ---- batch_pack.hip (before the network) ------------------------------------------------------------------------------
 struct sbgm_assemble_args;

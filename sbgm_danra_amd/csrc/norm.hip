@@ -355,9 +355,8 @@ int sbgm_launch_layernorm(const float* x, float* y, const float* gamma, const fl
     return 0;
 }
 
-int sbgm_launch_batchnorm_train(const float* x, float* y, const float* gamma, const float* beta, float* running_mean,
-                                float* running_var, const float* res, const float* tbias_after, int relu, int B,
-                                int HW, int C, float eps, float momentum, double* stats_ws, hipStream_t st, float* mr_out) {
+// first half of a train-mode BatchNorm: per-channel fp64 sums (x, x^2) of THIS process's batch into stats_ws[2C]
+int sbgm_launch_batchnorm_stats(const float* x, int B, int HW, int C, double* stats_ws, hipStream_t st) {
     SBGM_CHECK(C % 4 == 0 && C <= 1024, "batchnorm: C=%d unsupported", C);
     if (!sbgm_scratch_prezeroed) SBGM_HIP(hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * (size_t)C, st));
     // treat the batch as one long pixel axis: [B*HW][C]
@@ -369,9 +368,28 @@ int sbgm_launch_batchnorm_train(const float* x, float* y, const float* gamma, co
     hipLaunchKernelGGL(norm_stats_kernel<true>, dim3(chunks, 1), dim3(NORM_THREADS), 2 * C * sizeof(double), st, x,
                        stats_ws, n, C, 1, ppb);
     SBGM_LAUNCH_CHECK();
+    return 0;
+}
+
+// second half: finalise (mean, rstd) from the sums over n_total values per channel — the local B*HW, or the sum over all
+// ranks after the caller all-reduced stats_ws (SyncBatchNorm) — update the running statistics and apply
+int sbgm_launch_batchnorm_apply(const float* x, float* y, const float* gamma, const float* beta, float* running_mean,
+                                float* running_var, const float* res, const float* tbias_after, int relu, int B, int HW, int C,
+                                float eps, float momentum, double* stats_ws, double n_total, hipStream_t st, float* mr_out) {
+    SBGM_CHECK(C % 4 == 0 && C <= 1024, "batchnorm: C=%d unsupported", C);
+    SBGM_CHECK(n_total >= (double)B * HW, "batchnorm: n_total=%g is smaller than the local batch (%d x %d)", n_total, B, HW);
+    const int n = B * HW;
     float* mr = mr_out ? mr_out : reinterpret_cast<float*>(stats_ws + 2 * (size_t)C);
     hipLaunchKernelGGL(batchnorm_train_apply_kernel, dim3(stream_blocks((size_t)n * (C / 4))), dim3(256), 2 * C * sizeof(float), st, x, y,
-                       gamma, beta, res, tbias_after, relu, B, HW, C, stats_ws, mr, running_mean, running_var, (double)n, eps, momentum);
+                       gamma, beta, res, tbias_after, relu, B, HW, C, stats_ws, mr, running_mean, running_var, n_total, eps, momentum);
     SBGM_LAUNCH_CHECK();
     return 0;
+}
+
+int sbgm_launch_batchnorm_train(const float* x, float* y, const float* gamma, const float* beta, float* running_mean,
+                                float* running_var, const float* res, const float* tbias_after, int relu, int B,
+                                int HW, int C, float eps, float momentum, double* stats_ws, hipStream_t st, float* mr_out) {
+    if (sbgm_launch_batchnorm_stats(x, B, HW, C, stats_ws, st)) return 1;
+    return sbgm_launch_batchnorm_apply(x, y, gamma, beta, running_mean, running_var, res, tbias_after, relu, B, HW, C, eps, momentum,
+                                       stats_ws, (double)B * HW, st, mr_out);
 }

@@ -9,40 +9,9 @@
 // hipGraph replays for every step.
 #include "common.h"
 #include "kernels.h"
+#include "philox.h"
 
 namespace {
-
-__device__ __forceinline__ void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
-    const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
-    const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
-    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
-    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
-    c[1] = (uint32_t)p1;
-    c[3] = (uint32_t)p0;
-    c[0] = n0;
-    c[2] = n2;
-}
-
-// 4 standard normals for (seed, stream offset, index)
-__device__ __forceinline__ f32x4 philox_normal4(unsigned long long seed, unsigned long long offset, unsigned long long idx) {
-    uint32_t c[4] = {(uint32_t)idx, (uint32_t)(idx >> 32), (uint32_t)offset, (uint32_t)(offset >> 32)};
-    uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        philox_round(c, k0, k1);
-        k0 += 0x9E3779B9u;
-        k1 += 0xBB67AE85u;
-    }
-    const float u0 = ((float)(c[0] >> 8) + 0.5f) * (1.0f / 16777216.0f);   // (0,1)
-    const float u1 = ((float)(c[1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    const float u2 = ((float)(c[2] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    const float u3 = ((float)(c[3] >> 8) + 0.5f) * (1.0f / 16777216.0f);
-    const float r0 = sqrtf(-2.f * logf(u0)), r1 = sqrtf(-2.f * logf(u2));
-    float s0, c0, s1, c1;
-    sincosf(6.283185307179586f * u1, &s0, &c0);
-    sincosf(6.283185307179586f * u3, &s1, &c1);
-    return f32x4{r0 * c0, r0 * s0, r1 * c1, r1 * s1};
-}
 
 // Philox counter of quad i of a [B][H][W] batch.  Default: the quad index itself.  With a tile map (full-domain tiling,
 // SURVEY.md 8f rank 3) the counter is the quad's position in the DOMAIN, so pixels that several overlapping tiles share
@@ -118,6 +87,9 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ sc
 }
 
 // Langevin corrector: eps = 2 (snr*sqrt(CHW) / mean_b ||score_b||)^2 ;  x += eps*score + sqrt(2 eps) N(0,1)
+// Tile mode (nm.origins set: the samples are tiles of one domain): the step size of a tile uses that tile's OWN score norm
+// instead of the batch mean, so a tile's trajectory does not depend on which other tiles share its batch or its GPU
+// (the reference has no tiler, its batch-mean rule :201 applies to batches of independent samples).
 __global__ __launch_bounds__(256) void langevin_kernel(float* __restrict__ x, const float* __restrict__ score,
                                                        const float* __restrict__ z, float snr_noise_norm,
                                                        const double* __restrict__ sumsq,
@@ -128,10 +100,17 @@ __global__ __launch_bounds__(256) void langevin_kernel(float* __restrict__ x, co
     for (int b = 0; b < B; ++b) gn += (float)sqrt(sumsq[b]);
     gn /= (float)B;
     const float r = snr_noise_norm / gn;
-    const float eps = 2.f * (r * r);
-    const float nz = sqrtf(2.f * eps);
+    float eps = 2.f * (r * r);
+    float nz = sqrtf(2.f * eps);
+    const bool per_tile = nm.origins != nullptr;
+    const size_t per4 = n4 / (size_t)B;
     const unsigned long long off = state ? state->rng_offset : off_val;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        if (per_tile) {
+            const float rt = snr_noise_norm / (float)sqrt(sumsq[i / per4]);
+            eps = 2.f * (rt * rt);
+            nz = sqrtf(2.f * eps);
+        }
         const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
         const f32x4 sv = reinterpret_cast<const f32x4*>(score)[i];
         const f32x4 n = z ? reinterpret_cast<const f32x4*>(z)[i] : philox_normal4(seed, off, noise_index(nm, i));

@@ -49,6 +49,14 @@ class _NativeStep:
                     g["params"] = ps
         return loss
 
+    def state_dict(self):
+        """torch's layout; the shared device step counter is written out as one CLONE per parameter, so a stock
+        torch.optim.Adam that loads the checkpoint owns independent counters (it would otherwise advance the one shared
+        storage once per parameter and per step)."""
+        sd = super().state_dict()
+        sd["state"] = {k: ({**v, "step": v["step"].clone()} if torch.is_tensor(v.get("step")) else v) for k, v in sd["state"].items()}
+        return sd
+
     def _step_group(self, gi, group, params):
         dev = params[0].device
         first = self.state[params[0]]
@@ -78,6 +86,7 @@ class _NativeStep:
         b1, b2 = group["betas"]
         N.check(N.lib().sbgm_adam_step_batched(tab[1].data_ptr(), tab[2], tab[3], master.data_ptr(), float(group["lr"]), float(b1), float(b2),
                                                float(group["eps"]), float(group["weight_decay"]), self._decoupled, N.stream()))
+        N.bump_generation()                            # parameters were written through raw pointers (no version-counter bump)
 
 
 class Adam(_NativeStep, torch.optim.Adam):

@@ -39,6 +39,11 @@ def world() -> tuple[int, int]:
     return (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
 
 
+def barrier() -> None:
+    if world()[1] > 1:
+        dist.barrier()
+
+
 def shard_range(n_items: int, rank: int, world_size: int) -> range:
     """Contiguous, balanced split of n_items independent units (batches / tiles): first n%world ranks get one more."""
     q, r = divmod(n_items, world_size)
@@ -47,37 +52,58 @@ def shard_range(n_items: int, rank: int, world_size: int) -> range:
 
 
 class GradientBucket:
-    """Flattened fp32 gradient bucket + one sum all-reduce, averaged over ranks."""
+    """One flat fp32 gradient tensor + one sum all-reduce, averaged over ranks.
 
-    def __init__(self, params: Iterable[torch.nn.Parameter]):
+    `GradientBucket(model)` adopts the model's gradient ARENA (train_graph.GradArena): the native backward kernels write every
+    parameter gradient straight into its slice and `p.grad` is a view of it, so the exchange is the all-reduce alone — no
+    gather / scatter copies (the native Adam step reads the same memory through `p.grad`).  A gradient that did not land in the
+    arena (live `.grad` tensors from gradient accumulation, the ConvTranspose2d ablation weights, a CPU model) is copied in and
+    `p.grad` re-pointed at its slice, which keeps the result identical.
+    `GradientBucket(iterable of parameters)` (no arena) keeps the same interface with a private flat tensor."""
+
+    def __init__(self, model_or_params):
+        self.model = model_or_params if isinstance(model_or_params, torch.nn.Module) else None
+        params = self.model.parameters() if self.model is not None else model_or_params
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         if not self.params:
             raise ValueError("GradientBucket needs at least one trainable parameter")
-        dev = self.params[0].device
-        self.numel = sum(p.numel() for p in self.params)
-        self.flat = torch.zeros(self.numel, dtype=torch.float32, device=dev)
+        self._own = None
+        self.copies = 0                                 # gradients that had to be copied into the flat tensor (diagnostic)
+
+    def _layout(self):
+        """(flat tensor, [view per parameter])"""
+        if self.model is not None and self.params[0].is_cuda:
+            from .train_graph import arena_for
+            arena = arena_for(self.model)
+            if getattr(self, "_views_for", None) is not arena:
+                self._views = [arena.grad_of(p) for p in self.params]
+                self._views_for = arena
+            return arena.flat, self._views
+        if self._own is None:
+            dev = self.params[0].device
+            flat = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=dev)
+            views, off = [], 0
+            for p in self.params:
+                views.append(flat[off:off + p.numel()].view(p.shape))
+                off += p.numel()
+            self._own = (flat, views)
+        return self._own
 
     def all_reduce_(self) -> None:
         rank, ws = world()
         if ws == 1:
             return
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            if p.grad is None:
-                self.flat[off:off + n].zero_()
-            else:
-                self.flat[off:off + n].copy_(p.grad.reshape(-1))
-            off += n
-        dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
-        self.flat.div_(ws)
-        off = 0
-        for p in self.params:
-            n = p.numel()
-            if p.grad is None:
-                p.grad = torch.empty_like(p)
-            p.grad.copy_(self.flat[off:off + n].view_as(p))
-            off += n
+        flat, views = self._layout()
+        for p, v in zip(self.params, views):
+            g = p.grad
+            if g is None:
+                v.zero_()                               # unused parameter: contributes 0, stays without a gradient
+            elif g.data_ptr() != v.data_ptr():
+                v.copy_(g)
+                p.grad = v
+                self.copies += 1
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+        flat.div_(ws)
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0) -> None:

@@ -112,7 +112,7 @@ def _native_run(kind, score_model: ScoreNet, batch_size, num_steps, snr, eps, hw
             raise ValueError("tile_origins keys the in-kernel noise; it cannot be combined with injected noise")
     N.check(eng.lib.sbgm_sampler_run(eng.h, C.byref(a), N.stream()))
     if score_model.training:
-        eng.download_bn_stats(score_model)
+        eng.download_bn_stats(score_model, n_forwards=int(num_steps) * (2 if kind == N.SAMPLER_PC else 1))
     return out
 
 
@@ -197,10 +197,13 @@ def pc_sampler(score_model, marginal_prob_std, diffusion_coeff, batch_size=64, n
 
 def ode_sampler(score_model, marginal_prob_std, diffusion_coeff, num_steps=100, batch_size=64, atol=error_tolerance,
                 rtol=error_tolerance, device="cuda", z=None, eps=1e-3, img_size=64, y=None, cond_img=None, lsm_cond=None,
-                topo_cond=None, cfg=None):
+                topo_cond=None, cfg=None, *, return_nfev=False):
     """Probability-flow ODE via scipy RK45 (reference score_sampling.py:239-300).  Host-driven by construction
     (the solver lives in scipy); every right-hand-side evaluation is one native network evaluation.  Like the
-    reference it conditions on nothing but (x, t) and starts from 32x32 unless `z` is given."""
+    reference it conditions on nothing but (x, t) (:290) and starts from 32x32 unless `z` is given (:279-283).  The
+    right-hand side keeps the reference's precision: t goes to the network in fp32, g(t)^2 is squared in fp32 (:296) and
+    multiplies the float64 score.  Keyword-only `return_nfev` (not in the reference, which only logs the count) also
+    returns the number of right-hand-side evaluations."""
     from scipy import integrate
     ones = torch.ones(batch_size, device=device)
     if z is None:
@@ -211,15 +214,16 @@ def ode_sampler(score_model, marginal_prob_std, diffusion_coeff, num_steps=100, 
 
     def rhs(t, xflat):
         xs = torch.tensor(xflat, device=device, dtype=torch.float32).reshape(shape)
-        tt = torch.full((shape[0],), float(t), device=device, dtype=torch.float32)
+        tt = torch.tensor(np.ones((shape[0],)) * t, device=device, dtype=torch.float32)
         with torch.no_grad():
             s = score_model(xs, tt)
-        g = float(diffusion_coeff(torch.tensor(t)))
-        return -0.5 * g * g * s.cpu().numpy().reshape(-1).astype(np.float64)
+        g = diffusion_coeff(torch.tensor(t)).cpu().numpy()          # fp32 0-d array, as in the reference
+        return -0.5 * (g ** 2) * s.cpu().numpy().reshape(-1).astype(np.float64)
 
     res = integrate.solve_ivp(rhs, (1.0, eps), init_x.reshape(-1).cpu().numpy(), rtol=rtol, atol=atol, method="RK45")
     logger.info(f"Number of function evaluations: {res.nfev}")
-    return torch.tensor(res.y[:, -1], device=device).reshape(shape)
+    x = torch.tensor(res.y[:, -1], device=device).reshape(shape)
+    return (x, res.nfev) if return_nfev else x
 
 
 def edm_sigma_schedule(n_steps, sigma_min=0.002, sigma_max=80, rho=7.0, device="cuda"):

@@ -216,7 +216,7 @@ class _Engine:
         act = _ACT_CODE.get(dec.activation)
         if act is None:
             raise NotImplementedError(f"decoder activation {dec.activation} not implemented natively")
-        cfg = N.ModelConfig(n_lsm, n_topo, n_cond, enc.time_embedding, (C.c_int * 4)(*enc.block_layers), enc.n_heads,
+        cfg = N.ModelConfig(C.sizeof(N.ModelConfig), n_lsm, n_topo, n_cond, enc.time_embedding, (C.c_int * 4)(*enc.block_layers), enc.n_heads,
                             enc.num_classes or 0, dec.last_fmap_channels,
                             N.NORM_GROUP if dec.norm == "group" else N.NORM_INSTANCE, dec.gn_groups, act,
                             float(getattr(net, "sigma", 25.0)), 0 if dec.use_resize_conv else 1)
@@ -237,7 +237,7 @@ class _Engine:
 
     def upload(self, net: "ScoreNet"):
         sd = net.state_dict(keep_vars=True)
-        ver = tuple((k, v.data_ptr(), v._version) for k, v in sd.items())
+        ver = (N.generation(),) + tuple((k, v.data_ptr(), v._version) for k, v in sd.items())
         if ver == self.version:
             return
         missing = [k for k in self.names if k not in sd]
@@ -257,17 +257,18 @@ class _Engine:
         N.check(self.lib.sbgm_model_check_complete(self.h))
         self.version = ver
 
-    def download_bn_stats(self, net: "ScoreNet"):
-        """train-mode forwards update the engine's running statistics; mirror them into the module buffers"""
+    def download_bn_stats(self, net: "ScoreNet", n_forwards: int = 1):
+        """train-mode forwards update the engine's running statistics; mirror them into the module buffers
+        (`num_batches_tracked` advances by the number of network evaluations that ran, as nn.BatchNorm2d counts them)"""
         st = N.stream()
         with torch.no_grad():
             for k, v in net.state_dict(keep_vars=True).items():
                 if k.endswith("running_mean") or k.endswith("running_var"):
                     N.check(self.lib.sbgm_model_get_param(self.h, k.encode(), v.data_ptr(), v.numel(), st))
                 elif k.endswith("num_batches_tracked"):
-                    v += 1
+                    v += n_forwards
         sd = net.state_dict(keep_vars=True)
-        self.version = tuple((k, v.data_ptr(), v._version) for k, v in sd.items())
+        self.version = (N.generation(),) + tuple((k, v.data_ptr(), v._version) for k, v in sd.items())
 
 
 class ScoreNet(nn.Module):
@@ -395,21 +396,86 @@ marginal_prob_std_fn = functools.partial(marginal_prob_std, sigma=sigma)
 diffusion_coeff_fn = functools.partial(diffusion_coeff, sigma=sigma)
 
 
+class _DSMLossFn(torch.autograd.Function):
+    """mean_b sum_chw w * (score * std_b + z)^2 (reference score_unet.py:974-984) — csrc/dsm_loss.hip"""
+
+    @staticmethod
+    def forward(ctx, score, z, std, sdf, rng_state):
+        B, per = score.shape[0], score[0].numel()
+        lib = N.lib()
+        loss = torch.empty((), device=score.device)
+        partial = torch.empty(B * lib.sbgm_dsm_loss_blocks(per), dtype=torch.float64, device=score.device)
+        N.check(lib.sbgm_dsm_loss_fwd(score.data_ptr(), z.data_ptr(), std.data_ptr(), N.ptr(sdf), partial.data_ptr(), loss.data_ptr(),
+                                      N.ptr(rng_state), B, per, N.stream()))
+        ctx.save_for_backward(score, z, std, sdf)
+        return loss
+
+    @staticmethod
+    def backward(ctx, dloss):
+        score, z, std, sdf = ctx.saved_tensors
+        B, per = score.shape[0], score[0].numel()
+        dscore = torch.empty_like(score)
+        dloss = N.f32c(dloss)
+        N.check(N.lib().sbgm_dsm_loss_bwd(score.data_ptr(), z.data_ptr(), std.data_ptr(), N.ptr(sdf), dloss.data_ptr(),
+                                          dscore.data_ptr(), B, per, N.stream()))
+        return dscore, None, None, None, None
+
+
+_LOSS_RNG = {}       # device -> int64[2] (Philox seed, offset) used by captured (hipGraph) steps; advanced on the device
+
+
+def _loss_rng_state(dev):
+    st = _LOSS_RNG.get(dev)
+    if st is None:
+        from .score_sampling import _fresh_seed
+        st = _LOSS_RNG[dev] = torch.tensor([_fresh_seed(), 0], dtype=torch.int64, device=dev)
+    return st
+
+
 def loss_fn(model, x, marginal_prob_std, t_eps=1e-3, device=None, y=None, cond_img=None, lsm_cond=None,
-            topo_cond=None, sdf_cond=None):
-    """Denoising score-matching loss (reference score_unet.py:936-985): same RNG order (`rand(B)` then
-    `randn_like(x)`), same batch-size checks.  With grad enabled the network runs through train_graph.forward_train
-    (native forward + backward kernels); the few [B,1,H,W]-sized elementwise ops of the loss itself are tensor ops."""
-    random_t = torch.rand(x.shape[0], device=x.device) * (1.0 - t_eps) + t_eps
-    z = torch.randn_like(x)
-    std = marginal_prob_std(random_t)
-    perturbed_x = x + std[:, None, None, None] * z
+            topo_cond=None, sdf_cond=None, *, noise=None):
+    """Denoising score-matching loss (reference score_unet.py:936-985), same argument list, same batch-size checks, same order
+    of the two random draws (`t ~ U` then `z ~ N(0,1)`).  The perturbation x + sigma(t) z, the weighted squared-error reduction
+    and its backward are HIP kernels (csrc/dsm_loss.hip); with grad enabled the network runs through
+    train_graph.forward_train (native forward + backward kernels).
+
+    Noise: drawn inside the perturbation kernel (Philox) from a seed taken from torch's CPU generator per call, so
+    `torch.manual_seed` makes a run repeatable; while a hipGraph is being captured the seed / offset pair lives on the device
+    and the loss kernel advances it, so every replay perturbs with fresh noise.  Keyword-only `noise=(t, z)` (not in the
+    reference) injects the draws for parity runs.  `marginal_prob_std` must be the VE schedule of this module (any sigma)."""
+    N.require_device(x)
     for name, arr in (("cond_img", cond_img), ("lsm_cond", lsm_cond), ("topo_cond", topo_cond), ("y", y)):
         if arr is not None and arr.shape[0] != x.shape[0]:
             raise ValueError(f"Batch size mismatch: x={x.shape[0]}, {name}={arr.shape[0]}")
+    if getattr(marginal_prob_std, "func", marginal_prob_std) is not globals()["marginal_prob_std"]:
+        raise NotImplementedError("the native loss implements the VE-SDE marginal_prob_std of this module (reference "
+                                  "score_unet.py:881-897); pass functools.partial(marginal_prob_std, sigma=...)")
+    sigma = _sigma_of(marginal_prob_std)
+    xc = N.f32c(x)
+    B, per = xc.shape[0], xc[0].numel()
+    dev = xc.device
+    lib = N.lib()
+    t_in = z_in = None
+    if noise is not None:
+        t_in, z_in = N.f32c(noise[0].to(dev).view(-1)), N.f32c(noise[1].to(dev))
+        if t_in.numel() != B or z_in.shape != xc.shape:
+            raise ValueError(f"noise=(t, z) must have shapes [{B}] and {tuple(xc.shape)}")
+    capturing = torch.cuda.is_current_stream_capturing()
+    rng = _loss_rng_state(dev) if (noise is None and capturing) else None
+    seed = 0
+    if noise is None and not capturing:
+        from .score_sampling import _fresh_seed
+        seed = _fresh_seed()
+    random_t, std = torch.empty(B, device=dev), torch.empty(B, device=dev)
+    perturbed_x = torch.empty_like(xc)
+    z = z_in if z_in is not None else torch.empty_like(xc)
+    N.check(lib.sbgm_dsm_perturb(xc.data_ptr(), N.ptr(z_in), N.ptr(t_in), N.ptr(rng), seed, float(t_eps), sigma,
+                                 perturbed_x.data_ptr(), z.data_ptr(), random_t.data_ptr(), std.data_ptr(), B, per, N.stream()))
     score = model(perturbed_x, random_t, y=y, cond_img=cond_img, lsm_cond=lsm_cond, topo_cond=topo_cond)
+    N.require_device(score)
+    sdf = None
     if sdf_cond is not None:
-        w = (torch.sigmoid(sdf_cond) * 0.5 + 0.5).to(x.device)
-    else:
-        w = torch.ones_like(x)
-    return torch.mean(torch.sum(w * (score * std[:, None, None, None] + z) ** 2, dim=(1, 2, 3)))
+        sdf = N.f32c(sdf_cond.to(dev))
+        if sdf.shape != xc.shape:
+            sdf = sdf.expand_as(xc).contiguous()
+    return _DSMLossFn.apply(N.f32c(score), z, std, sdf, rng)

@@ -46,6 +46,13 @@ class SyntheticDownscalingDataset(Dataset):
         return item
 
 
-def synthetic_loader(cfg, batch_size, n_items=None, seed=42, shuffle=False, raw_geo=False) -> DataLoader:
+def synthetic_loader(cfg, batch_size, n_items=None, seed=42, shuffle=False, raw_geo=False, shard=None, drop_last=False) -> DataLoader:
+    """`shard=(rank, world)`: every rank iterates over its own 1/world of the items (torch DistributedSampler), so the
+    data-parallel replicas see different samples and the effective batch is batch_size * world."""
     n_items = n_items or 4 * batch_size
-    return DataLoader(SyntheticDownscalingDataset(cfg, n_items, seed, raw_geo), batch_size=batch_size, shuffle=shuffle, num_workers=0)
+    ds = SyntheticDownscalingDataset(cfg, n_items, seed, raw_geo)
+    if shard is not None and shard[1] > 1:
+        from torch.utils.data.distributed import DistributedSampler
+        smp = DistributedSampler(ds, num_replicas=shard[1], rank=shard[0], shuffle=shuffle, seed=seed, drop_last=drop_last)
+        return DataLoader(ds, batch_size=batch_size, sampler=smp, num_workers=0, drop_last=drop_last)
+    return DataLoader(ds, batch_size=batch_size, shuffle=shuffle, num_workers=0, drop_last=drop_last)

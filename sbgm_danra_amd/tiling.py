@@ -10,8 +10,11 @@ halo or stitching code exists there, so this module has no reference counterpart
 * `sbgm_stitch_tiles` blends the tiles with linear ramps over the overlap, normalised per pixel (a partition of unity).
 
 Multi-GPU: tiles are independent units -> rank r samples tiles r::world with no collective during sampling; one
-all_gather of the finished tiles precedes the stitch.  (The Langevin step size uses the mean score norm of the rank's
-own tile batch, score_sampling.py:201, so the tile->rank assignment is part of the result; documented, not hidden.)
+all-reduce of the finished tiles (every tile is written by exactly one rank, the others hold zeros) precedes the stitch.
+The result does NOT depend on the world size or on `tiles_per_batch`: with `tile_origins` the Langevin step size of a
+tile uses that tile's own score norm (csrc/sampler.hip; the reference's batch-mean rule, score_sampling.py:201, is for
+batches of independent samples), the noise is keyed by domain position and everything else in the network is per
+sample in eval mode.
 """
 from __future__ import annotations
 
@@ -107,26 +110,37 @@ class FullDomainTiler:
         Tiles are sharded over the ranks of the process group (if any) and, per rank, run in batches of
         `tiles_per_batch`; every batch shares `seed`, so the domain-keyed noise is identical wherever tiles overlap."""
         from .score_sampling import _fresh_seed
-        rank, world = parallel.world()
+        _, world = parallel.world()
         seed = _fresh_seed() if seed is None else seed
         if world > 1:                                  # one seed for the whole domain
             import torch.distributed as dist
             s = torch.tensor([seed], dtype=torch.int64, device=self.device)
             dist.broadcast(s, 0)
             seed = int(s.item())
-        mine = list(range(len(self)))[rank::world]
-        per = tiles_per_batch or max(1, len(mine))
-        out = torch.zeros(len(self), 1, self.tile, self.tile, device=self.device)
-        for i in range(0, len(mine), per):
-            idx = mine[i:i + per]
+        def run_batch(idx):
             cut = lambda f: None if f is None else self.extract(f, idx)   # noqa: E731
             yb = None if y is None else torch.full((len(idx),), int(y), dtype=torch.int64, device=self.device)
-            res = sampler(score_model, marginal_prob_std, diffusion_coeff, batch_size=len(idx), num_steps=num_steps,
-                          device=self.device, img_size=self.tile, y=yb, cond_img=cut(cond_img), lsm_cond=cut(lsm_cond),
-                          topo_cond=cut(topo_cond), seed=seed, tile_origins=self.origins_dev[idx].contiguous(),
-                          domain_width=self.Wd_pad, **sampler_kw)
-            out[idx] = res
-        if world > 1:
-            import torch.distributed as dist
-            dist.all_reduce(out)                       # each tile was written by exactly one rank, the others hold zeros
+            return sampler(score_model, marginal_prob_std, diffusion_coeff, batch_size=len(idx), num_steps=num_steps,
+                           device=self.device, img_size=self.tile, y=yb, cond_img=cut(cond_img), lsm_cond=cut(lsm_cond),
+                           topo_cond=cut(topo_cond), seed=seed, tile_origins=self.origins_dev[idx].contiguous(),
+                           domain_width=self.Wd_pad, **sampler_kw)
+        out = sample_tiles_sharded(len(self), run_batch, (1, self.tile, self.tile), self.device, tiles_per_batch)
         return self.stitch(out)
+
+
+def sample_tiles_sharded(n_tiles: int, run_batch, tile_shape, device, tiles_per_batch=None) -> torch.Tensor:
+    """Deal `n_tiles` independent tiles round-robin over the ranks of the process group (rank r owns tiles r::world), run this
+    rank's tiles through `run_batch(list of tile indices) -> [len, *tile_shape]` in batches of `tiles_per_batch`, and merge:
+    every tile is written by exactly one rank, the others hold zeros, so ONE sum all-reduce leaves all tiles on every rank.
+    No collective runs while the tiles are being sampled."""
+    rank, world = parallel.world()
+    mine = list(range(n_tiles))[rank::world]
+    per = tiles_per_batch or max(1, len(mine))
+    out = torch.zeros(n_tiles, *tile_shape, device=device)
+    for i in range(0, len(mine), per):
+        idx = mine[i:i + per]
+        out[idx] = run_batch(idx)
+    if world > 1:
+        import torch.distributed as dist
+        dist.all_reduce(out)
+    return out

@@ -61,10 +61,95 @@ def _zero_reset(dev):
     _GRAD[dev] = [torch.zeros(_GRAD_FLOATS, device=dev), 0]
 
 
+# ---- gradient arena ------------------------------------------------------------------------------------------------------
+# Every parameter gradient of a model lives in ONE flat fp32 tensor: the backward kernels write (or atomically accumulate) a
+# parameter's gradient straight into its slice, `p.grad` ends up as a view of that slice, so the data-parallel exchange is ONE
+# all-reduce over the flat tensor with no gather / scatter copies (parallel.GradientBucket adopts it) and the native Adam step
+# reads the same memory.  The arena is zeroed once per step by forward_train.  It is used when every `p.grad` is None at the start
+# of the step (`optimizer.zero_grad()` default); with live gradients (accumulation over several backward calls) the kernels
+# write fresh tensors and autograd adds them, exactly as before.
+class GradArena:
+    def __init__(self, net):
+        self.params = [p for p in net.parameters() if p.requires_grad]
+        self.index, off = {}, 0
+        for p in self.params:
+            self.index[p.data_ptr()] = (off, p.numel())
+            off += (p.numel() + 63) // 64 * 64
+        self.numel = off
+        self.flat = torch.zeros(off, dtype=torch.float32, device=self.params[0].device)
+        self.sig = self.signature(net)
+        self.claimed = set()
+
+    @staticmethod
+    def signature(net):
+        return tuple(p.data_ptr() for p in net.parameters() if p.requires_grad)
+
+    def begin_step(self):
+        self.flat.zero_()
+        self.claimed.clear()
+
+    def view(self, t):
+        """slice for parameter tensor `t` (the parameter itself or a same-size view of it), once per step; else None"""
+        e = self.index.get(t.data_ptr())
+        if e is None or e[1] != t.numel() or e[0] in self.claimed:
+            return None
+        self.claimed.add(e[0])
+        return self.flat[e[0]: e[0] + e[1]].view(t.shape)
+
+    def grad_of(self, p):
+        off, n = self.index[p.data_ptr()]
+        return self.flat[off: off + n].view(p.shape)
+
+
+_ACTIVE_ARENA = [None]
+
+
+def arena_for(net, create=True):
+    """the model's gradient arena (rebuilt when a parameter moved: .to(), load_state_dict(assign=True))"""
+    a = getattr(net, "_grad_arena", None)
+    if a is not None and a.sig != GradArena.signature(net):
+        a = None
+    if a is None and create:
+        a = GradArena(net)
+        object.__setattr__(net, "_grad_arena", a)
+    return a
+
+
+def _pgrad(arena, like, zeroed):
+    """storage for the gradient of parameter tensor `like`: (tensor shaped like it, True if it is known to be zero).
+    From the arena when one is active and the slice was not handed out yet this step, else a pooled / fresh tensor."""
+    if arena is not None:
+        v = arena.view(like)
+        if v is not None:
+            return v, True
+    if zeroed:
+        g, z = _grad_zeros(like.numel(), like.device)
+        return g.view(like.shape), z
+    return torch.empty_like(like), False
+
+
+# SyncBatchNorm (DESIGN.md 7): statistics summed over the ranks of the process group, see BNTrainFn
+_SYNC_BN = [False]
+_SYNC_COUNT = [None]            # total batch size over the ranks for the current forward (device-independent python int)
+
+
+def set_sync_batchnorm(on: bool):
+    prev = _SYNC_BN[0]
+    _SYNC_BN[0] = bool(on)
+    return prev
+
+
+def _sync_world():
+    import torch.distributed as dist
+    if _SYNC_BN[0] and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        return dist
+    return None
+
+
 # Gradients that are accumulated with atomics and RETURNED to autograd (conv biases, LayerNorm gamma/beta, time-bias sums,
 # the weights of 1x1 convolutions / linears) are slices of one tensor that forward_train allocates zeroed — a fresh tensor per step, so a slice that lives on as
 # some parameter's .grad is never touched by a later step (unlike the scratch pool above, which is re-zeroed in place).
-_GRAD_FLOATS = 8 << 20
+_GRAD_FLOATS = 2 << 20
 _GRAD = {}             # device -> [tensor, offset]
 
 
@@ -208,14 +293,16 @@ class ConvFn(torch.autograd.Function):
         oh, ow = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
         y = torch.empty(B, oh, ow, cout, device=x.device)
         _conv_launch(x, packed, y, cs, cout, k, stride, pad, bias, res, tbias)
-        ctx.save_for_backward(x, w)
+        ctx.save_for_backward(x, w, bias)
         ctx.geom = (stride, pad, bias is not None, res is not None, tbias is not None)
         ctx.packed_bwd = e["bwd"] if e is not None else None
+        ctx.arena = _ACTIVE_ARENA[0]
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, w = ctx.saved_tensors
+        x, w, bias = ctx.saved_tensors
+        arena = ctx.arena
         stride, pad, has_bias, has_res, has_tb = ctx.geom
         dy = dy.contiguous()
         B, H, W, cs = x.shape
@@ -234,13 +321,13 @@ class ConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             if k == 1 and cs == cin and cs % 64 == 0 and cout % 64 == 0:
                 # 1x1 / linear: the partial-sum slab has the OIHW layout, so the (zeroed) gradient itself is the workspace
-                ws, pooled = _grad_zeros(cout * cin, x.device)
-                dw = ws.view(cout, cin, 1, 1)
+                dw, pooled = _pgrad(arena, w, True)
+                ws = dw
             else:
-                dw = torch.empty_like(w)
+                dw, _ = _pgrad(arena, w, False)
                 ws, pooled = _zeros(k * k * cout * cs, x.device)
             if want_db and pooled:                               # bias gradient as a by-product of the weight-gradient sweep
-                db, _ = _grad_zeros(cout, x.device)              # a returned gradient: never a slice of the re-zeroed scratch pool
+                db, _ = _pgrad(arena, bias, True)                # a returned gradient: never a slice of the re-zeroed scratch pool
                 with _prezeroed(True):
                     N.check(_L().sbgm_conv2d_wgrad_bias(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), B, H, W,
                                                         cs, cin, cout, k, k, stride, pad, _st()))
@@ -250,7 +337,7 @@ class ConvFn(torch.autograd.Function):
                     N.check(_L().sbgm_conv2d_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), ws.data_ptr(), B, H, W, cs, cin, cout, k, k,
                                                    stride, pad, _st()))
         if want_db:
-            db = torch.empty(cout, device=x.device)
+            db, _ = _pgrad(arena, bias, False)
             N.check(_L().sbgm_colsum(dy.data_ptr(), None, db.data_ptr(), dy.numel() // cout, cout, _st()))
         dtb = None
         if has_tb and ctx.needs_input_grad[4]:
@@ -270,7 +357,10 @@ def linear(x2d, w, b, res=None):
 
 
 class BNTrainFn(torch.autograd.Function):
-    """y = relu?(BatchNorm_train(x) [+ res]) [+ tbias_after]; updates running statistics in place"""
+    """y = relu?(BatchNorm_train(x) [+ res]) [+ tbias_after]; updates running statistics in place.
+    With set_sync_batchnorm(True) and a process group of more than one rank the statistics (forward: sum x, sum x^2; backward:
+    sum g, sum g*xhat) are summed over the ranks — one small all-reduce each way — so the step equals the reference's
+    single-device step on the GLOBAL batch (reference score_unet.py:323 sees the whole batch on one device)."""
 
     @staticmethod
     def forward(ctx, x, gamma, beta, rm, rv, res, tb_after, relu, eps, momentum):
@@ -278,26 +368,51 @@ class BNTrainFn(torch.autograd.Function):
         y = torch.empty_like(x)
         mr = torch.empty(Cc, 2, device=x.device)         # (mean, rstd) per channel, kept for the backward
         sums, pooled = _zeros(4 * Cc, x.device)          # 2C fp64 sums: scratch of this launch only
+        dist = _sync_world()
+        n_total = None
         with _prezeroed(pooled):
-            N.check(_L().sbgm_batchnorm_train_fwd(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(),
-                                                  rv.data_ptr(), N.ptr(res), N.ptr(tb_after), int(relu), B, H * W, Cc, eps, momentum,
-                                                  sums.data_ptr(), mr.data_ptr(), _st()))
-        ctx.save_for_backward(x, y, gamma, tb_after, mr)
-        ctx.cfg = (relu, res is not None, tb_after is not None)
+            if dist is None:
+                N.check(_L().sbgm_batchnorm_train_fwd(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(),
+                                                      rv.data_ptr(), N.ptr(res), N.ptr(tb_after), int(relu), B, H * W, Cc, eps, momentum,
+                                                      sums.data_ptr(), mr.data_ptr(), _st()))
+            else:
+                n_total = float(_SYNC_COUNT[0] * H * W)
+                N.check(_L().sbgm_batchnorm_train_stats(x.data_ptr(), B, H * W, Cc, sums.data_ptr(), _st()))
+                dist.all_reduce(sums.view(torch.float64))
+                N.check(_L().sbgm_batchnorm_train_apply(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(),
+                                                        rv.data_ptr(), N.ptr(res), N.ptr(tb_after), int(relu), B, H * W, Cc, eps, momentum,
+                                                        sums.data_ptr(), n_total, mr.data_ptr(), _st()))
+        ctx.save_for_backward(x, y, gamma, beta, tb_after, mr)
+        ctx.cfg = (relu, res is not None, tb_after is not None, n_total)
+        ctx.arena = _ACTIVE_ARENA[0]
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, y, gamma, tb_after, mr = ctx.saved_tensors
-        relu, has_res, has_tb = ctx.cfg
+        x, y, gamma, beta, tb_after, mr = ctx.saved_tensors
+        relu, has_res, has_tb, n_total = ctx.cfg
         dy = dy.contiguous()
         B, H, W, Cc = x.shape
         dx, dres = torch.empty_like(x), (torch.empty_like(x) if has_res else None)
-        dg, db = torch.empty(Cc, device=x.device), torch.empty(Cc, device=x.device)
+        dg, _ = _pgrad(ctx.arena, gamma, False)
+        db, _ = _pgrad(ctx.arena, beta, False)
         s12, pooled = _zeros(B * Cc * 2, x.device)
         with _prezeroed(pooled):
-            N.check(_L().sbgm_batchnorm_bwd(x.data_ptr(), dy.data_ptr(), y.data_ptr(), gamma.data_ptr(), N.ptr(tb_after), mr.data_ptr(), int(relu),
-                                            dx.data_ptr(), N.ptr(dres), dg.data_ptr(), db.data_ptr(), s12.data_ptr(), B, H * W, Cc, _st()))
+            if n_total is None:
+                N.check(_L().sbgm_batchnorm_bwd(x.data_ptr(), dy.data_ptr(), y.data_ptr(), gamma.data_ptr(), N.ptr(tb_after), mr.data_ptr(),
+                                                int(relu), dx.data_ptr(), N.ptr(dres), dg.data_ptr(), db.data_ptr(), s12.data_ptr(), B, H * W,
+                                                Cc, _st()))
+            else:
+                dist = _sync_world()
+                if dist is None:
+                    raise RuntimeError("SyncBatchNorm backward without the process group its forward ran in")
+                N.check(_L().sbgm_batchnorm_bwd_reduce(x.data_ptr(), dy.data_ptr(), y.data_ptr(), N.ptr(tb_after), mr.data_ptr(), int(relu),
+                                                       s12.data_ptr(), B, H * W, Cc, _st()))
+                tot = s12.view(B, Cc * 2).sum(0)
+                dist.all_reduce(tot)
+                N.check(_L().sbgm_batchnorm_bwd_apply(x.data_ptr(), dy.data_ptr(), y.data_ptr(), gamma.data_ptr(), N.ptr(tb_after),
+                                                      mr.data_ptr(), int(relu), dx.data_ptr(), N.ptr(dres), dg.data_ptr(), db.data_ptr(),
+                                                      s12.data_ptr(), tot.data_ptr(), n_total, B, H * W, Cc, _st()))
         dtb = None
         if has_tb:
             dtb, zeroed = _grad_zeros(B * Cc, x.device)
@@ -320,6 +435,7 @@ class GroupNormFn(torch.autograd.Function):
                                         Cc, G, eps, ws.data_ptr(), mr.data_ptr(), _st()))
         ctx.save_for_backward(x, gamma, beta, skip, tbias, mr)
         ctx.cfg = (act, G)
+        ctx.arena = _ACTIVE_ARENA[0]
         return y
 
     @staticmethod
@@ -331,8 +447,8 @@ class GroupNormFn(torch.autograd.Function):
         dev = x.device
         dx = torch.empty_like(x)
         dskip = torch.empty_like(x) if skip is not None else None
-        dg = torch.empty(Cc, device=dev) if gamma is not None else None
-        db = torch.empty(Cc, device=dev) if gamma is not None else None
+        dg = _pgrad(ctx.arena, gamma, False)[0] if gamma is not None else None
+        db = _pgrad(ctx.arena, beta, False)[0] if gamma is not None else None
         dtb = torch.empty(B, Cc, device=dev) if tbias is not None else None
         s12, pooled = _zeros(B * Cc * 2, dev)
         with _prezeroed(pooled):
@@ -348,18 +464,23 @@ class LayerNormFn(torch.autograd.Function):
         M, Cc = x.shape
         y = torch.empty_like(x)
         N.check(_L().sbgm_layernorm_fwd(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), M, Cc, eps, _st()))
-        ctx.save_for_backward(x, gamma)
+        ctx.save_for_backward(x, gamma, beta)
         ctx.eps = eps
+        ctx.arena = _ACTIVE_ARENA[0]
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, gamma = ctx.saved_tensors
+        x, gamma, beta = ctx.saved_tensors
         dy = dy.contiguous()
         M, Cc = x.shape
         dx = torch.empty_like(x)
-        dgb, zeroed = _grad_zeros(2 * Cc, x.device)
-        dg, db = dgb[:Cc], dgb[Cc:]                      # adjacent: the launcher zeroes both with one memset (none if pooled)
+        dg, z1 = _pgrad(ctx.arena, gamma, True)
+        db, z2 = _pgrad(ctx.arena, beta, True)
+        zeroed = z1 and z2
+        if not zeroed:                                   # adjacent: the launcher zeroes both with one memset
+            dgb = torch.empty(2 * Cc, device=x.device)
+            dg, db = dgb[:Cc], dgb[Cc:]
         with _prezeroed(zeroed):
             N.check(_L().sbgm_layernorm_bwd(x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), M,
                                             Cc, ctx.eps, _st()))
@@ -459,22 +580,25 @@ class TimeProjFn(torch.autograd.Function):
         N.check(_L().sbgm_time_proj_fwd(t.data_ptr(), N.ptr(y), N.ptr(table) if y is not None else None, freqs.data_ptr(),
                                         weight.data_ptr(), bias.data_ptr(), out.data_ptr(), semb.data_ptr(), raw.data_ptr(), B, D, ch,
                                         _st()))
-        ctx.save_for_backward(weight, semb, raw, y if y is not None else torch.empty(0), table if table is not None else torch.empty(0))
+        ctx.save_for_backward(weight, bias, semb, raw, y if y is not None else torch.empty(0), table if table is not None else torch.empty(0))
         ctx.has_y = y is not None
+        ctx.arena = _ACTIVE_ARENA[0]
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        weight, semb, raw, y, table = ctx.saved_tensors
+        weight, bias, semb, raw, y, table = ctx.saved_tensors
         dout = dout.contiguous()
         B, (ch, D) = dout.shape[0], weight.shape
-        dW, db = torch.empty_like(weight), torch.empty(ch, device=dout.device)
+        dW, db = _pgrad(ctx.arena, weight, False)[0], _pgrad(ctx.arena, bias, False)[0]
         demb = torch.zeros(B, D, device=dout.device) if ctx.has_y else None
         N.check(_L().sbgm_time_proj_bwd(dout.data_ptr(), weight.data_ptr(), semb.data_ptr(), raw.data_ptr(), dW.data_ptr(), db.data_ptr(),
                                         N.ptr(demb), B, D, ch, _st()))
         dtable = None
         if ctx.has_y:
-            dtable = torch.zeros_like(table)
+            dtable, was_zero = _pgrad(ctx.arena, table, True)
+            if not was_zero:
+                dtable.zero_()
             N.check(_L().sbgm_label_emb_bwd(demb.data_ptr(), y.data_ptr(), dtable.data_ptr(), B, D, _st()))
         return None, None, dtable, None, dW, db
 
@@ -490,19 +614,21 @@ class Cout1Fn(torch.autograd.Function):
         out = torch.empty(B, 1, H, W, device=a.device)
         N.check(_L().sbgm_conv3x3_cout1_fwd(a.data_ptr(), wp.data_ptr(), bias.data_ptr(), t.data_ptr(), sigma, out.data_ptr(), B, H, W, Cc,
                                             _st()))
-        ctx.save_for_backward(a, wp, t)
+        ctx.save_for_backward(a, wp, t, w, bias)
         ctx.sigma = sigma
+        ctx.arena = _ACTIVE_ARENA[0]
         return out
 
     @staticmethod
     def backward(ctx, dout):
-        a, wp, t = ctx.saved_tensors
+        a, wp, t, w, bias = ctx.saved_tensors
         dout = dout.contiguous()
         B, H, W, Cc = a.shape
-        da, dwp, db = torch.empty_like(a), torch.empty(9 * Cc, device=a.device), torch.empty(1, device=a.device)
+        da, dwp, db = torch.empty_like(a), torch.empty(9 * Cc, device=a.device), _pgrad(ctx.arena, bias, False)[0]
         N.check(_L().sbgm_conv3x3_cout1_bwd(dout.data_ptr(), a.data_ptr(), wp.data_ptr(), t.data_ptr(), ctx.sigma, da.data_ptr(),
                                             dwp.data_ptr(), db.data_ptr(), B, H, W, Cc, _st()))
-        dw = dwp.view(3, 3, Cc).permute(2, 0, 1).reshape(1, Cc, 3, 3).contiguous()      # [tap][c] -> OIHW
+        dw, _ = _pgrad(ctx.arena, w, False)
+        dw.view(Cc, 9).copy_(dwp.view(9, Cc).t())                                        # [tap][c] -> OIHW
         return da, dw, db, None, None
 
 
@@ -550,11 +676,22 @@ def forward_train(net, x, t, y, cond, lsm, topo):
     _ACTIVE_PLAN[0] = plan
     _NBT.clear()
     _zero_reset(x.device)
+    arena = None
+    if all(p.grad is None for p in net.parameters()):      # fresh step: gradients go straight into the model's flat arena
+        arena = arena_for(net)
+        arena.begin_step()
+    _ACTIVE_ARENA[0] = arena
+    dist = _sync_world()
+    if dist is not None:                                    # SyncBatchNorm: total batch over the ranks (ragged last batches allowed)
+        cnt = torch.tensor([float(x.shape[0])], device=x.device)
+        dist.all_reduce(cnt)
+        _SYNC_COUNT[0] = int(round(float(cnt.item())))
     plan.run(x.device)
     try:
         return _forward_train(net, x, t, y, cond, lsm, topo)
     finally:
         _ACTIVE_PLAN[0] = None
+        _ACTIVE_ARENA[0] = None
 
 
 def _forward_train(net, x, t, y, cond, lsm, topo):

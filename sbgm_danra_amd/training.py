@@ -140,13 +140,25 @@ class TrainingPipeline_general:
             self.optimizer.zero_grad(set_to_none=True)
             with torch.cuda.graph(graph):
                 loss = fwd_bwd()
-            ent = g[key] = (graph, static, loss)
+            # each capture leaves ITS gradient tensors in .grad (graph-pool memory, or the model's arena): keep them with the
+            # graph, so that replaying an older graph after a newer capture hands the optimizer the tensors that replay wrote
+            params = [p for p in self.model.parameters() if p.grad is not None]
+            ent = g[key] = (graph, static, loss, params, [p.grad for p in params])
+            self._graph_live = key
             # the capture itself did not execute: the replay below is this batch's step
-        graph, static, loss = ent
+        graph, static, loss, params, grads = ent
         for s_, t in zip(static, live):
             if s_ is not None:
                 s_.copy_(t)
         graph.replay()
+        if getattr(self, "_graph_live", None) != key or (params and params[0].grad is not grads[0]):
+            for p in self.model.parameters():
+                p.grad = None
+            for p, gr in zip(params, grads):
+                p.grad = gr
+            self._graph_live = key
+        from . import _native
+        _native.bump_generation()       # the replay moved BatchNorm running statistics / num_batches_tracked without a version bump
         return x, loss
 
     def train_batches(self, dataloader, epochs=10, current_epoch=1, verbose=True, use_mixed_precision=False):
@@ -154,7 +166,7 @@ class TrainingPipeline_general:
             raise NotImplementedError("fp32 only: the reference's autocast branch is commented out (training.py:325-343)")
         self.model.train()
         if self._bucket is None and parallel.world()[1] > 1:
-            self._bucket = parallel.GradientBucket(self.model.parameters())
+            self._bucket = parallel.GradientBucket(self.model)
         loss_sum = 0.0
         use_graph = bool(self.cfg["training"].get("use_hip_graph", False)) and torch.device(self.device).type == "cuda"
         for idx, samples in enumerate(dataloader):
@@ -195,10 +207,12 @@ class TrainingPipeline_general:
             val_loss = self.validate_batches(val_dataloader, verbose)
             train_losses.append(train_loss)
             val_losses.append(val_loss)
-            if val_loss < best and parallel.world()[0] == 0:
+            if val_loss < best:
                 best = val_loss
-                self.save_model(self.checkpoint_dir, self.checkpoint_name)
-                logger.info(f"→ Best model saved with validation loss: {best:.4f} at epoch {epoch}.")
+                if parallel.world()[0] == 0:
+                    self.save_model(self.checkpoint_dir, self.checkpoint_name)
+                    logger.info(f"→ Best model saved with validation loss: {best:.4f} at epoch {epoch}.")
+            parallel.barrier()            # the other ranks read rank 0's checkpoint in generate_and_plot_samples
             with open(os.path.join(self.path_losses, f"losses_{self.model_string}.pkl"), "wb") as f:
                 pickle.dump({"train_losses": train_losses, "val_losses": val_losses}, f)
             if cfg["visualization"].get("create_figs") and cfg["data_handling"].get("n_gen_samples", 0) > 0 and gen_dataloader is not None:

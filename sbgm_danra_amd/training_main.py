@@ -22,7 +22,7 @@ def train_main(cfg, loaders=None):
         device = torch.device("cuda", local)
     else:
         device = torch.device("cpu")
-    train_dl, val_dl, gen_dl = loaders if loaders is not None else get_dataloader(cfg)
+    train_dl, val_dl, gen_dl = loaders if loaders is not None else get_dataloader(cfg, shard=(rank, world))
     seed = cfg["training"]["seed"]
     torch.manual_seed(seed)
     torch.cuda.manual_seed(seed)
@@ -35,6 +35,12 @@ def train_main(cfg, loaders=None):
                                     diffusion_coeff_fn=diffusion_coeff_fn, optimizer=optimizer, device=device,
                                     lr_scheduler=scheduler, cfg=cfg)
     parallel.broadcast_parameters(model)
+    if world > 1:                 # identical weights everywhere (above), but every replica draws its OWN loss noise (t, z) and
+        torch.manual_seed(seed + rank)   # dropout flags: with one shared stream the replicas' gradients would be copies of each other
+        torch.cuda.manual_seed(seed + rank)
+    if cfg["training"].get("sync_batchnorm", False):
+        from .train_graph import set_sync_batchnorm
+        set_sync_batchnorm(True)
     ckpt = os.path.join(ckpt_dir, ckpt_name)
     if cfg["training"].get("load_checkpoint") and os.path.exists(ckpt):
         pipe.load_checkpoint(ckpt, load_ema=cfg["training"].get("load_ema", False))

@@ -76,12 +76,15 @@ def get_scheduler(cfg, optimizer):
     raise ValueError(f"Scheduler {kind} not recognized.")
 
 
-def get_dataloader(cfg):
-    """-> (train, val, gen) loaders of synthetic batches (see module docstring)."""
+def get_dataloader(cfg, shard=None):
+    """-> (train, val, gen) loaders of synthetic batches (see module docstring).  `shard=(rank, world)` splits the training
+    items over the data-parallel ranks (the reference's train loader drops the ragged last batch, data_modules / training_utils
+    `drop_last=True`; kept here so every rank runs the same number of steps); validation and generation stay whole on every rank."""
     bs = cfg["training"]["batch_size"]
     n_gen = max(1, int(cfg["data_handling"].get("n_gen_samples", 1) or 1))
-    return (synthetic_loader(cfg, bs, n_items=4 * bs, seed=1), synthetic_loader(cfg, bs, n_items=2 * bs, seed=2),
-            synthetic_loader(cfg, n_gen, n_items=n_gen, seed=3))
+    world = shard[1] if shard else 1
+    return (synthetic_loader(cfg, bs, n_items=4 * bs * world, seed=1, shard=shard, drop_last=True),
+            synthetic_loader(cfg, bs, n_items=2 * bs, seed=2), synthetic_loader(cfg, n_gen, n_items=n_gen, seed=3))
 
 
 def get_gen_dataloader(cfg):

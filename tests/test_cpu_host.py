@@ -101,7 +101,7 @@ def test_library_exports_every_declared_symbol():
     assert len(declared) >= 35
     assert declared == set(N.SIGNATURES), declared ^ set(N.SIGNATURES)
     lib = N.lib()                                # dlopen + resolve all of them (no compute, no GPU needed)
-    assert lib.sbgm_abi_version() == 1
+    assert lib.sbgm_abi_version() == 2
     raw = ctypes.CDLL(N.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name
@@ -208,3 +208,139 @@ def _sharded_sampling_case(rank, world, out_dir):
 def test_sampling_shards_without_collectives(tmp_path):
     _spawn(_sharded_sampling_case, tmp_path)
     assert (tmp_path / "ok.pt").exists()
+
+
+# ---- the C ABI's structs: header == ctypes binding == documented binding ------------------------------------------------
+def _header_structs():
+    """{struct name: [field names in order]} for every `typedef struct ... { } name;` of include/sbgm_hip.h"""
+    hdr = open(os.path.join(ROOT, "include", "sbgm_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", " ", hdr, flags=re.S)
+    out = {}
+    for body, name in re.findall(r"typedef\s+struct\s+\w+\s*\{(.*?)\}\s*(\w+)\s*;", hdr, flags=re.S):
+        fields = []
+        for decl in body.split(";"):
+            decl = decl.strip()
+            if not decl:
+                continue
+            for d in decl.split(","):
+                m = re.search(r"(\w+)\s*(\[[^\]]*\])?\s*$", d.strip())
+                fields.append(m.group(1))
+        out[name] = fields
+    return out
+
+
+def test_header_structs_match_the_bindings(tmp_path):
+    """field count / order of every struct in the header == the ctypes classes of _native.py == the snippet in INTEGRATION.md,
+    and sizeof() agrees with a gcc-compiled probe of the header (a binding copied from stale documentation once made
+    sbgm_model_create read past the caller's struct)"""
+    import subprocess
+    structs = _header_structs()
+    pairs = {"sbgm_model_config": N.ModelConfig, "sbgm_sampler_args": N.SamplerArgs, "sbgm_conv_args": N.ConvArgs,
+             "sbgm_pack_desc": N.PackDesc, "sbgm_adam_desc": N.AdamDesc, "sbgm_profile": N.Profile, "sbgm_assemble_args": N.AssembleArgs}
+    assert set(structs) == set(pairs), set(structs) ^ set(pairs)
+    for cname, cls in pairs.items():
+        assert structs[cname] == [f[0] for f in cls._fields_], cname
+    assert structs["sbgm_model_config"][0] == "struct_size"
+    # sizeof from the C compiler
+    src = tmp_path / "probe.c"
+    src.write_text('#include <stdio.h>\n#include "sbgm_hip.h"\nint main(void){' +
+                   "".join(f'printf("{c} %zu\\n", sizeof({c}));' for c in pairs) + "return 0;}\n")
+    exe = tmp_path / "probe"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    sizes = dict(l.split() for l in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    for cname, cls in pairs.items():
+        assert int(sizes[cname]) == ctypes.sizeof(cls), (cname, sizes[cname], ctypes.sizeof(cls))
+    assert N.lib().sbgm_model_config_size() == ctypes.sizeof(N.ModelConfig)
+    # the documented binding
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    block = doc[doc.index("class ModelConfig(C.Structure)"):]
+    block = block[:block.index("def check")]
+    assert re.findall(r'\("(\w+)",', block) == structs["sbgm_model_config"]
+    ctor = re.search(r"cfg = ModelConfig\((.*)\)\n", doc).group(1)
+    assert ctor.startswith("C.sizeof(ModelConfig)")
+
+
+def test_model_create_rejects_a_config_from_another_header():
+    """no GPU needed: the size check precedes every allocation"""
+    lib = N.lib()
+    h = ctypes.c_void_p()
+    good = ctypes.sizeof(N.ModelConfig)
+    for bad in (0, 2, good - 4, good + 4):          # 0 / 2 = what an old binding (first field n_lsm_channels) would put there
+        cfg = N.ModelConfig(bad, 0, 0, 1, 256, (ctypes.c_int * 4)(2, 2, 2, 2), 4, 0, 512, 1, 8, 2, 25.0, 0)
+        assert lib.sbgm_model_create(ctypes.byref(cfg), ctypes.byref(h)) != 0 and not h.value
+        assert b"struct_size" in lib.sbgm_last_error()
+
+
+# ---- bench.py as its own multi-GPU launcher ------------------------------------------------------------------------------
+@pytest.mark.parametrize("mode", ["sample", "train", "domain"])
+def test_bench_spawns_its_own_ranks(mode):
+    """`python bench.py --gpus N` (how the driver calls it) must start N rank processes itself; dry-run: the ranks only report"""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SBGM_BENCH_DRYRUN"] = "1"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "3", "--steps", "2", "--warmup", "1", "--mode", mode],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1                                       # rank 0's line only
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 3 and out["mode"] == mode and out["master"].startswith("127.0.0.1:")
+
+
+# ---- gradient arena / bucket ----------------------------------------------------------------------------------------------
+def _bucket_views_case(rank, world, out_dir):
+    torch.manual_seed(0)
+    net = nn.Sequential(nn.Conv2d(2, 4, 3, padding=1), nn.GroupNorm(2, 4), nn.Conv2d(4, 1, 1), nn.Linear(6, 6))
+    net[3].weight.requires_grad_(False)                          # frozen parameter: not part of the bucket
+    parallel.broadcast_parameters(net)
+    bucket = parallel.GradientBucket(net)
+    x = torch.randn(4, 2, 6, 6, generator=torch.Generator().manual_seed(rank))
+    for step in range(2):
+        net.zero_grad(set_to_none=True)
+        (net(x) ** 2).mean().backward()
+        local = [p.grad.clone() for p in net.parameters() if p.requires_grad]
+        bucket.all_reduce_()
+        flat, views = bucket._layout()
+        assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(bucket.params, views))
+        torch.save(local, os.path.join(out_dir, f"local{rank}_{step}.pt"))
+        torch.save([p.grad.clone() for p in bucket.params], os.path.join(out_dir, f"avg{rank}_{step}.pt"))
+
+
+def test_gradient_bucket_on_a_model_repoints_grads_into_the_flat_tensor(tmp_path):
+    _spawn(_bucket_views_case, tmp_path)
+    for step in range(2):
+        l0, l1, a0, a1 = (torch.load(tmp_path / f"{n}_{step}.pt", weights_only=True) for n in ("local0", "local1", "avg0", "avg1"))
+        for x0, x1, y0, y1 in zip(l0, l1, a0, a1):
+            assert torch.equal(y0, y1) and torch.allclose(y0, (x0 + x1) / 2, rtol=1e-6, atol=1e-8)
+
+
+# ---- full-domain tiles over ranks (stub sampler) ---------------------------------------------------------------------------
+def _stub_tiles(idx):                                # a tile's result depends on its index only (as with per-tile Langevin norms)
+    return torch.stack([torch.full((1, 4, 4), float(i + 1)) * torch.arange(16.).view(1, 4, 4) for i in idx])
+
+
+def _tile_shard_case(rank, world, out_dir):
+    from sbgm_danra_amd.tiling import sample_tiles_sharded
+    want = _stub_tiles(list(range(7)))
+    calls = []
+
+    def run(idx):
+        calls.append(list(idx))
+        return _stub_tiles(idx)
+    for per in (None, 1, 2):
+        calls.clear()
+        got = sample_tiles_sharded(7, run, (1, 4, 4), "cpu", per)
+        assert torch.equal(got, want)
+        assert sorted(sum(calls, [])) == list(range(7))[rank::world]
+        assert all(len(c) <= (per or 7) for c in calls)
+    torch.save(True, os.path.join(out_dir, f"ok{rank}.pt"))
+
+
+def test_tile_sharding_is_world_size_invariant(tmp_path):
+    """rank r runs tiles r::world, one all-reduce merges them: the merged tile set equals the single-process result, for ragged
+    counts, for tiles_per_batch smaller than a rank's share, and no collective runs while tiles are being sampled"""
+    from sbgm_danra_amd.tiling import sample_tiles_sharded
+    _spawn(_tile_shard_case, tmp_path)
+    assert (tmp_path / "ok0.pt").exists() and (tmp_path / "ok1.pt").exists()
+    assert torch.equal(sample_tiles_sharded(7, _stub_tiles, (1, 4, 4), "cpu", 3), _stub_tiles(list(range(7))))      # world size 1

@@ -1,6 +1,8 @@
-"""Training path on the GPU: every native backward kernel against PyTorch-CPU autograd of the same op, then the whole
-loss_fn gradient against the golden vectors captured from the reference (tests/golden/loss_b2_64.npz) and a two-step
-Adam trajectory against the CPU oracle.  Tolerance: 1e-4 max-rel on gradients (fp32 atomics reorder sums)."""
+"""Training path on the GPU: every native backward kernel against PyTorch-CPU autograd of the same op, the ConvTranspose2d
+ablation decoder against the reference's goldens, every parameter gradient of a 7-channel model against CPU autograd of the
+oracle and a two-step SGD trajectory.  (loss_fn itself vs the reference's golden loss / gradients: test_gpu_loss.py; the
+C3-shaped step: test_gpu_configs.py.)  Tolerance: 1e-4 max-rel on gradients (fp32 atomics reorder sums), where
+max-rel = max|a - b| / max|b| over the whole tensor."""
 import math
 import os
 
@@ -181,25 +183,6 @@ def test_final_conv_backward():
     assert maxrel(nchw(ad.grad.cpu()), ar.grad) < GT and maxrel(wd.grad.cpu(), wr.grad) < GT and maxrel(bd.grad.cpu(), br.grad) < GT
 
 
-def test_loss_gradients_match_reference_goldens(golden_dir):
-    """loss value + gradients of the 7 probe parameters recorded from the reference's loss_fn + backward"""
-    import sbgm_danra_amd as S
-    g = load_golden(os.path.join(golden_dir, "loss_b2_64.npz"))
-    _, net, _ = build_pair(1)
-    net.train()
-    x, cond, sdf, t, z = (g[k].cuda() for k in ("x", "cond_img", "sdf", "t", "z"))
-    std = S.marginal_prob_std_fn(t)
-    score = net(x + std[:, None, None, None] * z, t, cond_img=cond)
-    wgt = torch.sigmoid(sdf) * 0.5 + 0.5
-    loss = torch.mean(torch.sum(wgt * (score * std[:, None, None, None] + z) ** 2, dim=(1, 2, 3)))
-    loss.backward()
-    assert abs(float(loss) / float(g["loss"]) - 1) < 1e-5
-    params = dict(net.named_parameters())
-    for k in [k for k in g if k.startswith("grad::")]:
-        gr = params[k[6:]].grad.reshape(-1).cpu()
-        assert maxrel(gr[:: max(1, gr.numel() // 2048)][:2048], g[k]) < 2e-4, k
-
-
 def test_transpose_decoder_matches_reference_goldens(golden_dir):
     """the ConvTranspose2d ablation decoder (model.use_resize_conv = false): forward, loss and gradients vs the reference"""
     import sbgm_danra_amd as S
@@ -214,16 +197,16 @@ def test_transpose_decoder_matches_reference_goldens(golden_dir):
                            cond_img=cond, seed=3)
     assert torch.isfinite(got).all()
     net.train()
-    tu, zu = g["t_used"].cuda(), g["z_used"].cuda()
-    std = S.marginal_prob_std_fn(tu)
-    score = net(x + std[:, None, None, None] * zu, tu, cond_img=cond)
-    loss = torch.mean(torch.sum((score * std[:, None, None, None] + zu) ** 2, dim=(1, 2, 3)))
+    loss = S.loss_fn(net, x, S.marginal_prob_std_fn, cond_img=cond, noise=(g["t_used"].cuda(), g["z_used"].cuda()))
     loss.backward()
     assert abs(float(loss) / float(g["loss"]) - 1) < 1e-5
     params = dict(net.named_parameters())
+    worst = {}
     for k in [k for k in g if k.startswith("grad_sub::")]:
         gr = params[k[10:]].grad.reshape(-1).cpu()
-        assert maxrel(gr[:: (257 if gr.numel() > 4096 else 1)][:4096], g[k]) < 5e-4, k
+        worst[k] = maxrel(gr[:: (257 if gr.numel() > 4096 else 1)][:4096], g[k])
+    print("transpose decoder probe-gradient max-rel:", {k: f"{v:.2e}" for k, v in worst.items()})
+    assert max(worst.values()) < GT, worst
 
 
 def _batch(gen, B=3, hw=64):
@@ -236,9 +219,8 @@ def _batch(gen, B=3, hw=64):
 
 
 def _native_loss(net, S, x, cond, lsm, topo, y, t, z):
-    std = S.marginal_prob_std_fn(t.cuda())
-    sc = net(x.cuda() + std[:, None, None, None] * z.cuda(), t.cuda(), y.cuda(), cond.cuda(), lsm.cuda(), topo.cuda())
-    return torch.mean(torch.sum((sc * std[:, None, None, None] + z.cuda()) ** 2, dim=(1, 2, 3)))
+    return S.loss_fn(net, x.cuda(), S.marginal_prob_std_fn, y=y.cuda(), cond_img=cond.cuda(), lsm_cond=lsm.cuda(), topo_cond=topo.cuda(),
+                     noise=(t.cuda(), z.cuda()))
 
 
 def test_every_parameter_gradient_matches_the_oracle():
@@ -262,7 +244,8 @@ def test_every_parameter_gradient_matches_the_oracle():
             continue
         errs[k] = maxrel(pn[k].grad.cpu(), p.grad)
     worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
-    assert worst[0][1] < 5e-4, worst
+    print("all-parameter gradients vs oracle (B=3, 64x64, 7 channels), worst max-rel:", [(k, f"{v:.2e}") for k, v in worst])
+    assert worst[0][1] < GT, worst
     # BatchNorm running statistics moved identically
     so, sn = ora.state_dict(), net.state_dict()
     for k in so:

@@ -254,3 +254,45 @@ def test_errors_are_loud():
     loss.backward()
     assert torch.isfinite(loss) and all(p.grad is not None and torch.isfinite(p.grad).all()
                                         for k, p in net.named_parameters() if not k.startswith("decoder.final_layer.time_"))
+
+
+def test_ode_sampler_matches_reference_golden(golden_dir):
+    """ode_sampler (reference score_sampling.py:239-300): scipy RK45 around native network evaluations, start z injected.
+    The solver's step control reacts to fp32-level differences of the right-hand side, so the endpoint is compared at 1e-3
+    and the evaluation count within 2 % (golden: 974 evaluations at rtol = atol = 1e-5, 224 at 1e-3)."""
+    import sbgm_danra_amd as S
+    g = load_golden(os.path.join(golden_dir, "ode_b2_32.npz"))
+    _, net, _ = build_pair(0)
+    net.eval()
+    for tol, tag in ((1e-3, "tol1e-3"), (1e-5, "tol1e-5")):
+        got, nfev = S.ode_sampler(net, S.marginal_prob_std_fn, S.diffusion_coeff_fn, batch_size=2, device="cuda", z=g["z"].cuda(),
+                                  atol=tol, rtol=tol, return_nfev=True)
+        want, nref = g[f"x_{tag}"], int(g[f"nfev_{tag}"])
+        err = maxrel(got.cpu(), want)
+        print(f"ode_sampler {tag}: max-rel {err:.2e}, nfev {nfev} (reference {nref})")
+        assert got.dtype == torch.float64 and got.shape == (2, 1, 32, 32)       # res.y is float64 in the reference too (:297)
+        assert err <= 1e-3 and abs(nfev - nref) <= max(6, 0.02 * nref)
+    # default start: 32x32 draws scaled by marginal_prob_std(1), like the reference (:279-281)
+    torch.manual_seed(3)
+    out = S.ode_sampler(net, S.marginal_prob_std_fn, S.diffusion_coeff_fn, batch_size=1, device="cuda", atol=1e-2, rtol=1e-2)
+    assert out.shape == (1, 1, 32, 32) and torch.isfinite(out).all()
+
+
+def test_pc_sampler_with_train_mode_batchnorm_matches_reference_golden(golden_dir):
+    """literal launch_generation behaviour (evaluate_sbgm/generation.py:47 never calls .eval()): BatchNorm batch statistics
+    inside the sampler, B = 4 at 64x64 (well-conditioned statistics, so the usual sampler tolerance applies)"""
+    import sbgm_danra_amd as S
+    g = load_golden(os.path.join(golden_dir, "pc_trainbn_b4_64_2steps.npz"))
+    _, net, _ = build_pair(1)
+    net.train()
+    with torch.no_grad():
+        got = S.pc_sampler(net, S.marginal_prob_std_fn, S.diffusion_coeff_fn, batch_size=4, num_steps=2, device="cuda", img_size=64,
+                           cond_img=g["cond_img"].cuda(), noise=g["noise"])
+    err = maxrel(got.cpu(), g["x_mean"])
+    print(f"train-mode BatchNorm PC sampler (B=4, 64x64, 2 steps): max-rel {err:.2e}")
+    assert err <= 1e-3
+    sd = net.state_dict()
+    assert maxrel(sd["encoder.bn1.running_mean"].cpu(), g["bn1_running_mean"]) <= 1e-4
+    assert maxrel(sd["encoder.bn1.running_var"].cpu(), g["bn1_running_var"]) <= 1e-4
+    assert maxrel(sd["encoder.layer4.1.bn2.running_var"].cpu(), g["l4_running_var"]) <= 1e-3
+    assert int(sd["encoder.bn1.num_batches_tracked"]) == int(g["num_batches_tracked"]) == 4      # 2 steps x 2 evaluations

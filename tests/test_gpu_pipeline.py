@@ -202,3 +202,100 @@ def test_training_step_as_hip_graph(cfg_path):
     assert np.isfinite(b) and int(model.encoder.bn1.num_batches_tracked) == 6 and len(pipe._graphs) == 1
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for k, p in model.named_parameters()
                if not k.startswith("decoder.final_layer.time_"))
+
+
+def _graph_pipe(cfg_path, **training_overrides):
+    from sbgm.score_unet import diffusion_coeff_fn, loss_fn, marginal_prob_std_fn
+    from sbgm.training import TrainingPipeline_general
+    from sbgm.training_utils import get_model, get_optimizer
+    from sbgm.utils import load_config
+    cfg = load_config(cfg_path)
+    cfg.training.use_hip_graph = True
+    cfg.monitoring.extreme_prcp.enabled = False
+    for k, v in training_overrides.items():
+        setattr(cfg.training, k, v)
+    torch.manual_seed(0)
+    model, _, _ = get_model(cfg)
+    pipe = TrainingPipeline_general(model, loss_fn, marginal_prob_std_fn, diffusion_coeff_fn, get_optimizer(cfg, model),
+                                    torch.device("cuda"), None, cfg)
+    return cfg, model, pipe
+
+
+def test_evaluation_after_graph_training_sees_the_trained_weights(cfg_path):
+    """hipGraph replays and the native Adam step change weights and BatchNorm buffers without touching torch's version counters;
+    the inference engine must still re-upload them: after graph-mode training, model.eval() must equal a FRESH ScoreNet loaded
+    from model.state_dict() (validation and best-checkpoint selection depend on it)."""
+    from sbgm.training_utils import get_model
+    from sbgm_danra_amd.synthetic_data import synthetic_loader
+    from sbgm_danra_amd.utils import extract_samples
+    cfg, model, pipe = _graph_pipe(cfg_path)
+    dl = synthetic_loader(cfg, 2, n_items=4)
+    batch = next(iter(dl))
+    x, seasons, cond, _h, lsm, _s, topo, _a, _b = extract_samples(batch, "cuda")
+    t = torch.tensor([0.3, 0.7], device="cuda")
+    model.eval()
+    with torch.no_grad():
+        before = model(x, t, seasons, cond, lsm, topo).clone()           # the engine uploads the initial weights here
+    pipe.train_batches(dl, epochs=2, current_epoch=1, verbose=False)      # capture + replays + native Adam steps
+    pipe.train_batches(dl, epochs=2, current_epoch=2, verbose=False)      # replays only
+    model.eval()
+    with torch.no_grad():
+        after = model(x, t, seasons, cond, lsm, topo)
+    fresh, _, _ = get_model(cfg)
+    fresh.load_state_dict(model.state_dict())
+    fresh.eval()
+    with torch.no_grad():
+        want = fresh(x, t, seasons, cond, lsm, topo)
+    assert not torch.equal(before, after)
+    assert torch.equal(after, want)
+    # and the pipeline's own validation runs on the current weights
+    v1 = pipe.validate_batches(dl, verbose=False)
+    pipe.train_batches(dl, epochs=3, current_epoch=3, verbose=False)
+    v2 = pipe.validate_batches(dl, verbose=False)
+    assert np.isfinite(v1) and np.isfinite(v2)
+
+
+def test_graph_steps_with_two_batch_shapes_use_their_own_gradients(cfg_path):
+    """a ragged last batch captures a second graph; replaying the FIRST graph afterwards must hand the optimizer the gradients
+    that replay wrote (each capture allocates its own .grad tensors): interleaved graph steps == eager steps"""
+    from sbgm_danra_amd.synthetic_data import synthetic_loader
+    from sbgm_danra_amd.utils import extract_samples
+    cfg, model, pipe = _graph_pipe(cfg_path)
+    model.train()
+    big = next(iter(synthetic_loader(cfg, 3, n_items=3, seed=5)))
+    small = next(iter(synthetic_loader(cfg, 1, n_items=1, seed=6)))
+
+    def eager_grads(batch, noise):
+        for p in model.parameters():
+            p.grad = None
+        x, seasons, cond, _h, lsm, sdf, topo, _a, _b = extract_samples(batch, "cuda")
+        pipe.loss_fn(model, x, pipe.marginal_prob_std_fn, y=seasons, cond_img=cond, lsm_cond=lsm, topo_cond=topo,
+                     sdf_cond=sdf if pipe.sdf_weighted_loss else None, noise=noise).backward()
+        return {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+
+    # graph steps draw their noise on the device; read it back through a wrapper model so the eager run can reuse it
+    import sbgm_danra_amd.score_unet as SU
+    sd0 = {k: v.clone() for k, v in model.state_dict().items()}
+    seq = [big, small, big, small, big]
+    for i, batch in enumerate(seq):
+        model.load_state_dict(sd0)                      # same weights for every comparison (no optimizer step in between)
+        _, loss = pipe._graph_step(batch)
+        torch.cuda.synchronize()
+        got = {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}
+        assert torch.isfinite(loss)
+        # recompute the same step eagerly: reproduce the graph's draw (seed, offset - 1 after the loss advanced it)
+        st = SU._loss_rng_state(torch.device("cuda", torch.cuda.current_device()))
+        seed, off = int(st[0]), int(st[1]) - 1
+        x = extract_samples(batch, "cuda")[0]
+        B, per = x.shape[0], x[0].numel()
+        lib = SU.N.lib()
+        state = torch.tensor([seed, off], dtype=torch.int64, device="cuda")
+        xp, z, tt, sd_ = torch.empty_like(x), torch.empty_like(x), torch.empty(B, device="cuda"), torch.empty(B, device="cuda")
+        SU.N.check(lib.sbgm_dsm_perturb(x.data_ptr(), None, None, state.data_ptr(), 0, 1e-3, 25.0, xp.data_ptr(), z.data_ptr(), tt.data_ptr(),
+                                        sd_.data_ptr(), B, per, SU.N.stream()))
+        model.load_state_dict(sd0)
+        want = eager_grads(batch, (tt, z))
+        assert got.keys() == want.keys()
+        worst = max(float((got[k] - want[k]).abs().max() / want[k].abs().max().clamp_min(1e-30)) for k in want)
+        assert worst < 1e-4, (i, worst)
+    assert len(pipe._graphs) == 2

@@ -1,0 +1,144 @@
+"""SyncBatchNorm for the data-parallel training step (new capability; BASELINE config 3 is "batch 64 on 8 GPUs", and the
+reference's BatchNorm sees the whole batch on one device, score_unet.py:323):
+
+1. the two-halves kernels (`sbgm_batchnorm_train_stats/_apply`, `sbgm_batchnorm_bwd_reduce/_apply`) with the rank sums added by
+   hand reproduce the whole-batch forward / backward;
+2. two rank processes (gloo process group, both on this box's one GPU): with `set_sync_batchnorm(True)` the averaged
+   gradients of 2 x B/2 equal the single-process gradients of the full batch; without it they do not (per-replica statistics).
+"""
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+from sbgm_danra_amd import _native as N  # noqa: E402
+from util_models import build_pair, maxrel  # noqa: E402
+
+
+def test_split_batchnorm_kernels_reproduce_the_whole_batch():
+    lib, st = N.lib(), N.stream
+    B, H, W, Cc = 6, 8, 8, 64
+    g = torch.Generator().manual_seed(2)
+    x = (torch.randn(B, H, W, Cc, generator=g) * 2 + 0.5).cuda()
+    gamma, beta = torch.randn(Cc, generator=g).cuda(), torch.randn(Cc, generator=g).cuda()
+    res, tb = torch.randn(B, H, W, Cc, generator=g).cuda(), torch.randn(B, Cc, generator=g).cuda()
+    dy = torch.randn(B, H, W, Cc, generator=g).cuda()
+    n_total = float(B * H * W)
+
+    def whole():
+        y, mr = torch.empty_like(x), torch.empty(Cc, 2, device="cuda")
+        rm, rv = torch.zeros(Cc, device="cuda"), torch.ones(Cc, device="cuda")
+        ws = torch.zeros(6 * Cc, device="cuda")
+        N.check(lib.sbgm_batchnorm_train_fwd(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(),
+                                             res.data_ptr(), tb.data_ptr(), 1, B, H * W, Cc, 1e-5, 0.1, ws.data_ptr(), mr.data_ptr(), st()))
+        dx, dres = torch.empty_like(x), torch.empty_like(x)
+        dg, db = torch.empty(Cc, device="cuda"), torch.empty(Cc, device="cuda")
+        s12 = torch.zeros(B * Cc * 2, device="cuda")
+        N.check(lib.sbgm_batchnorm_bwd(x.data_ptr(), dy.data_ptr(), y.data_ptr(), gamma.data_ptr(), tb.data_ptr(), mr.data_ptr(), 1,
+                                       dx.data_ptr(), dres.data_ptr(), dg.data_ptr(), db.data_ptr(), s12.data_ptr(), B, H * W, Cc, st()))
+        return y, rm, rv, dx, dres, dg, db
+
+    y0, rm0, rv0, dx0, dres0, dg0, db0 = whole()
+    parts = [slice(0, 2), slice(2, 6)]                     # two "ranks" with unequal batches
+    stats = []
+    for sl in parts:
+        ws = torch.zeros(6 * Cc, device="cuda")
+        xs = x[sl].contiguous()
+        N.check(lib.sbgm_batchnorm_train_stats(xs.data_ptr(), xs.shape[0], H * W, Cc, ws.data_ptr(), st()))
+        stats.append(ws)
+    summed = stats[0].view(torch.float64)[:2 * Cc] + stats[1].view(torch.float64)[:2 * Cc]         # the all-reduce
+    ys, mrs, s12s, rms = [], [], [], []
+    for sl in parts:
+        xs, rs, tbs = x[sl].contiguous(), res[sl].contiguous(), tb[sl].contiguous()
+        ws = torch.zeros(6 * Cc, device="cuda")
+        ws.view(torch.float64)[:2 * Cc] = summed
+        y, mr = torch.empty_like(xs), torch.empty(Cc, 2, device="cuda")
+        rm, rv = torch.zeros(Cc, device="cuda"), torch.ones(Cc, device="cuda")
+        N.check(lib.sbgm_batchnorm_train_apply(xs.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(), rv.data_ptr(),
+                                               rs.data_ptr(), tbs.data_ptr(), 1, xs.shape[0], H * W, Cc, 1e-5, 0.1, ws.data_ptr(), n_total,
+                                               mr.data_ptr(), st()))
+        ys.append(y), mrs.append(mr), rms.append((rm, rv))
+        s12 = torch.zeros(xs.shape[0] * Cc * 2, device="cuda")
+        dys = dy[sl].contiguous()
+        N.check(lib.sbgm_batchnorm_bwd_reduce(xs.data_ptr(), dys.data_ptr(), y.data_ptr(), tbs.data_ptr(), mr.data_ptr(), 1, s12.data_ptr(),
+                                              xs.shape[0], H * W, Cc, st()))
+        s12s.append(s12)
+    assert maxrel(torch.cat(ys).cpu(), y0.cpu()) < 1e-6
+    for rm, rv in rms:                                     # every rank ends with the global running statistics
+        assert maxrel(rm.cpu(), rm0.cpu()) < 1e-6 and maxrel(rv.cpu(), rv0.cpu()) < 1e-6
+    tot = sum(s.view(-1, Cc * 2).sum(0) for s in s12s).contiguous()                                   # the all-reduce
+    dxs, dress, dgs, dbs = [], [], [], []
+    for sl, y, mr, s12 in zip(parts, ys, mrs, s12s):
+        xs, tbs, dys = x[sl].contiguous(), tb[sl].contiguous(), dy[sl].contiguous()
+        dx, dres = torch.empty_like(xs), torch.empty_like(xs)
+        dg, db = torch.empty(Cc, device="cuda"), torch.empty(Cc, device="cuda")
+        N.check(lib.sbgm_batchnorm_bwd_apply(xs.data_ptr(), dys.data_ptr(), y.data_ptr(), gamma.data_ptr(), tbs.data_ptr(), mr.data_ptr(), 1,
+                                             dx.data_ptr(), dres.data_ptr(), dg.data_ptr(), db.data_ptr(), s12.data_ptr(), tot.data_ptr(),
+                                             n_total, xs.shape[0], H * W, Cc, st()))
+        dxs.append(dx), dress.append(dres), dgs.append(dg), dbs.append(db)
+    assert maxrel(torch.cat(dxs).cpu(), dx0.cpu()) < 1e-5 and maxrel(torch.cat(dress).cpu(), dres0.cpu()) < 1e-6
+    assert maxrel((dgs[0] + dgs[1]).cpu(), dg0.cpu()) < 1e-5 and maxrel((dbs[0] + dbs[1]).cpu(), db0.cpu()) < 1e-5   # local sums add up
+
+
+def _batch(B=4, hw=64):
+    g = torch.Generator().manual_seed(123)
+    return (torch.randn(B, 1, hw, hw, generator=g), torch.randn(B, 1, hw, hw, generator=g), torch.rand(B, generator=g) * 0.9 + 0.05,
+            torch.randn(B, 1, hw, hw, generator=g))
+
+
+def _rank_main(rank, world, port, sync, out_dir):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    import sbgm_danra_amd as S
+    from sbgm_danra_amd import parallel
+    from sbgm_danra_amd.train_graph import set_sync_batchnorm
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        _, net, _ = build_pair(1)
+        net.train()
+        set_sync_batchnorm(sync)
+        x, cond, t, z = _batch()
+        sl = slice(rank * 2, rank * 2 + 2)
+        loss = S.loss_fn(net, x[sl].cuda(), S.marginal_prob_std_fn, cond_img=cond[sl].cuda(), noise=(t[sl].cuda(), z[sl].cuda()))
+        loss.backward()
+        bucket = parallel.GradientBucket(net)
+        bucket.all_reduce_()
+        torch.cuda.synchronize()
+        if rank == 0:
+            torch.save({"copies": bucket.copies, "grads": {k: p.grad.cpu() for k, p in net.named_parameters() if p.grad is not None},
+                        "bn1_rv": net.state_dict()["encoder.bn1.running_var"].cpu()}, os.path.join(out_dir, f"sync{int(sync)}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_two_rank_step_with_syncbn_equals_the_full_batch_step(tmp_path):
+    import sbgm_danra_amd as S
+    _, net, _ = build_pair(1)
+    net.train()
+    x, cond, t, z = _batch()
+    loss = S.loss_fn(net, x.cuda(), S.marginal_prob_std_fn, cond_img=cond.cuda(), noise=(t.cuda(), z.cuda()))
+    loss.backward()
+    want = {k: p.grad.cpu() for k, p in net.named_parameters() if p.grad is not None}
+    want_rv = net.state_dict()["encoder.bn1.running_var"].cpu()
+    for sync in (True, False):
+        mp.spawn(_rank_main, args=(2, _free_port(), sync, str(tmp_path)), nprocs=2, join=True)
+    got = torch.load(tmp_path / "sync1.pt", weights_only=True)
+    assert got["copies"] == 0                          # every gradient was produced inside the arena: the exchange copied nothing
+    errs = {k: maxrel(got["grads"][k], want[k]) for k in want}
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:3]
+    print("SyncBatchNorm 2 ranks vs full batch, worst gradient max-rel:", worst)
+    assert got["grads"].keys() == want.keys() and worst[0][1] < 2e-4, worst
+    assert maxrel(got["bn1_rv"], want_rv) < 1e-5
+    plain = torch.load(tmp_path / "sync0.pt", weights_only=True)
+    assert max(maxrel(plain["grads"][k], want[k]) for k in want) > 1e-2      # per-replica statistics are a different step
