@@ -1089,7 +1089,7 @@ int sbgm_launch_conv_wgrad(const float* dy, const float* x, float* dw_oihw, floa
     int pps = ((M + splits - 1) / splits + 3) / 4 * 4;
     splits = (M + pps - 1) / pps;
     const size_t n = (size_t)KH * KW * Cout * Cs;
-    if (!sbgm_scratch_prezeroed && dbias) SBGM_HIP(hipMemsetAsync(dbias, 0, (size_t)Cout * 4, st));
+    if (!sbgm_scratch_prezeroed && dbias) { if (sbgm_zero_async(dbias, (size_t)Cout * 4, st)) return 1; }
     const size_t dy_b = (size_t)M * Cout * 4, x_b = (size_t)B * H * W * Cs * 4;
     const bool lds16 = W % 16 == 0 && H % 16 == 0, lds8 = W == 8 && H == 8;
     if (KH == 3 && KW == 3 && S == 1 && PAD == 1 && Cs % 32 == 0 && (lds16 || lds8) && dy_b < (1ull << 31) && x_b < (1ull << 31) &&
@@ -1108,7 +1108,7 @@ int sbgm_launch_conv_wgrad(const float* dy, const float* x, float* dw_oihw, floa
             attr_set = true;
         }
         float* direct = grid_lds.y == 1 ? dw_oihw : nullptr;          // no pixel split: no atomics, no slab, no unpack pass
-        if (!direct && !sbgm_scratch_prezeroed) SBGM_HIP(hipMemsetAsync(dwp_ws, 0, n * 4, st));
+        if (!direct && !sbgm_scratch_prezeroed) { if (sbgm_zero_async(dwp_ws, n * 4, st)) return 1; }
         if (lds16)
             hipLaunchKernelGGL(conv3x3_wgrad_lds_kernel<16>, grid_lds, dim3(WG_THREADS), (size_t)(WG_DY_FLOATS + WgTile<16>::X_FLOATS) * 4, st,
                                dy, x, dwp_ws, dbias, B, H, W, Cs, Cout, tpw, (uint32_t)dy_b, (uint32_t)x_b, direct, Cin);
@@ -1144,7 +1144,7 @@ int sbgm_launch_conv_wgrad(const float* dy, const float* x, float* dw_oihw, floa
         // (zeroed) gradient tensor as workspace and no unpack pass is needed
         const bool aliased = dwp_ws == dw_oihw;
         SBGM_CHECK(!aliased || (KH * KW == 1 && Cs == Cin), "wgrad: ws may alias dw only for 1x1 kernels with c_pad == Cin");
-        if (!direct && !sbgm_scratch_prezeroed) SBGM_HIP(hipMemsetAsync(dwp_ws, 0, n * 4, st));
+        if (!direct && !sbgm_scratch_prezeroed) { if (sbgm_zero_async(dwp_ws, n * 4, st)) return 1; }
         const TapGeom tg{M, OH, OW, H, W, S, PAD, KW, KH * KW, stem ? 1 : 0};
         hipLaunchKernelGGL(conv_tap_wgrad_lds_kernel, grid_lds, dim3(WG_THREADS), lds, st, dy, x, dwp_ws, dbias, tg, Cs, Cout, tpw,
                            (uint32_t)dy_b, (uint32_t)x_b, direct, Cin);
@@ -1160,7 +1160,7 @@ int sbgm_launch_conv_wgrad(const float* dy, const float* x, float* dw_oihw, floa
         }
         return 0;
     }
-    if (!sbgm_scratch_prezeroed) SBGM_HIP(hipMemsetAsync(dwp_ws, 0, n * 4, st));
+    if (!sbgm_scratch_prezeroed) { if (sbgm_zero_async(dwp_ws, n * 4, st)) return 1; }
     dim3 grid((tiles + 3) / 4, splits);
 #define SBGM_WG(F) hipLaunchKernelGGL(conv_wgrad_kernel<F>, grid, dim3(256), 0, st, dy, x, dwp_ws, B, H, W, Cs, OH, OW, Cout, KH, KW, S, PAD, pps, dbias)
     if (fci == 4) SBGM_WG(4); else if (fci == 2) SBGM_WG(2); else SBGM_WG(1);
@@ -1173,7 +1173,7 @@ int sbgm_launch_conv_wgrad(const float* dy, const float* x, float* dw_oihw, floa
 }
 
 int sbgm_launch_colsum(const float* x, const float* y, float* out, int M, int C, hipStream_t st) {
-    SBGM_HIP(hipMemsetAsync(out, 0, (size_t)C * 4, st));
+    { if (sbgm_zero_async(out, (size_t)C * 4, st)) return 1; }
     const int slabs = std::max(1, std::min(512, M / 64));
     const int rpb = (M + slabs - 1) / slabs;
     hipLaunchKernelGGL(colsum_kernel, dim3((C + 255) / 256, (M + rpb - 1) / rpb), dim3(256), 0, st, x, y, out, M, C, rpb);
@@ -1182,7 +1182,7 @@ int sbgm_launch_colsum(const float* x, const float* y, float* out, int M, int C,
 }
 
 int sbgm_launch_samplesum(const float* x, float* out, int B, int HW, int C, hipStream_t st) {
-    if (!sbgm_scratch_prezeroed) SBGM_HIP(hipMemsetAsync(out, 0, (size_t)B * C * 4, st));
+    if (!sbgm_scratch_prezeroed) { if (sbgm_zero_async(out, (size_t)B * C * 4, st)) return 1; }
     const int chunks = std::max(1, std::min(64, HW / 64));
     const int ppb = (HW + chunks - 1) / chunks;
     hipLaunchKernelGGL(samplesum_kernel, dim3((HW + ppb - 1) / ppb, B), dim3(256), 0, st, x, out, HW, C, ppb);
@@ -1192,7 +1192,7 @@ int sbgm_launch_samplesum(const float* x, float* out, int B, int HW, int C, hipS
 
 static int norm_bwd_reduce(bool bn, const NormBwdArgs& a, hipStream_t st) {
     SBGM_CHECK(a.C % 4 == 0 && a.C <= 1024, "norm_bwd: C=%d unsupported", a.C);
-    if (!sbgm_scratch_prezeroed) SBGM_HIP(hipMemsetAsync(a.s12, 0, (size_t)a.B * a.C * 2 * 4, st));
+    if (!sbgm_scratch_prezeroed) { if (sbgm_zero_async(a.s12, (size_t)a.B * a.C * 2 * 4, st)) return 1; }
     const int lanes_px = std::max(1, 256 / (a.C / 4));
     int chunks = std::max(1, std::min(256, a.HW / (lanes_px * 4)));      // measured: 4 px per thread; 16 was 7 % slower per step
     const int ppb = (a.HW + chunks - 1) / chunks;
@@ -1258,10 +1258,10 @@ int sbgm_launch_layernorm_bwd(const float* x, const float* dy, const float* gamm
     SBGM_CHECK(C <= 64 * LN_MAX_K, "layernorm_bwd: C=%d > %d", C, 64 * LN_MAX_K);
     if (sbgm_scratch_prezeroed) {
     } else if (dbeta == dgamma + C) {                     // one [2][C] tensor: one memset
-        SBGM_HIP(hipMemsetAsync(dgamma, 0, (size_t)C * 8, st));
+        { if (sbgm_zero_async(dgamma, (size_t)C * 8, st)) return 1; }
     } else {
-        SBGM_HIP(hipMemsetAsync(dgamma, 0, (size_t)C * 4, st));
-        SBGM_HIP(hipMemsetAsync(dbeta, 0, (size_t)C * 4, st));
+        { if (sbgm_zero_async(dgamma, (size_t)C * 4, st)) return 1; }
+        { if (sbgm_zero_async(dbeta, (size_t)C * 4, st)) return 1; }
     }
     const int rpw = std::max(1, M / 1024);               // ~256 blocks of 4 waves
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((M + 4 * rpw - 1) / (4 * rpw)), dim3(256), (size_t)8 * C * sizeof(float), st, x, dy, gamma,
@@ -1273,7 +1273,7 @@ int sbgm_launch_layernorm_bwd(const float* x, const float* dy, const float* gamm
 int sbgm_launch_mha_core_bwd(const float* qkv, const float* dout, float* dqkv, int B, int S, int C, int heads, hipStream_t st) {
     SBGM_CHECK(heads > 0 && C % heads == 0, "mha_bwd: C=%d heads=%d", C, heads);
     SBGM_CHECK((size_t)2 * 16 * S * 4 <= 150 * 1024, "mha_bwd: S=%d too long for the LDS-resident score rows", S);
-    SBGM_HIP(hipMemsetAsync(dqkv, 0, (size_t)B * S * 3 * C * 4, st));
+    { if (sbgm_zero_async(dqkv, (size_t)B * S * 3 * C * 4, st)) return 1; }
     const int blocks = B * heads * ((S + 15) / 16);
     const int d = C / heads;
     const size_t lds_staged = ((size_t)(2 * S + 32) * (d + 1) + (size_t)32 * S) * 4;
@@ -1304,8 +1304,8 @@ int sbgm_launch_cout1_bwd(const float* dout, const float* a, const float* w_tap_
     hipLaunchKernelGGL(cout1_bwd_data_kernel, dim3(stream_blocks((size_t)B * H * W * (C / 4))), dim3(256), 0, st, dout, w_tap_c, t, sigma,
                        da, B, H, W, C);
     SBGM_LAUNCH_CHECK();
-    SBGM_HIP(hipMemsetAsync(dw_tap_c, 0, (size_t)9 * C * 4, st));
-    SBGM_HIP(hipMemsetAsync(dbias, 0, 4, st));
+    { if (sbgm_zero_async(dw_tap_c, (size_t)9 * C * 4, st)) return 1; }
+    { if (sbgm_zero_async(dbias, 4, st)) return 1; }
     const int rows = B * H, rpb = std::max(1, rows / 256);
     hipLaunchKernelGGL(cout1_bwd_weight_kernel, dim3((rows + rpb - 1) / rpb), dim3(256), 0, st, dout, a, t, sigma, dw_tap_c, dbias, B, H,
                        W, C, rpb);

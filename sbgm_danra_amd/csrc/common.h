@@ -28,6 +28,11 @@ void sbgm_set_error(const char* fmt, ...);
     } while (0)
 #define SBGM_LAUNCH_CHECK() SBGM_HIP(hipGetLastError())
 
+// Zero `bytes` (a multiple of 4) of device memory with a KERNEL on `st` (pointwise.hip).  Used instead of hipMemsetAsync in every
+// launcher that can run under stream capture: a 196 KB memset node captured into a hipGraph (attention backward's dqkv) was
+// observed to leave garbage from the second replay on (ROCm 7.2), while kernel nodes replay faithfully.
+int sbgm_zero_async(void* p, size_t bytes, hipStream_t st);
+
 // ---- activation codes (shared by epilogues) ----------------------------------------------------
 enum { SBGM_ACT_NONE = 0, SBGM_ACT_RELU = 1, SBGM_ACT_SILU = 2, SBGM_ACT_GELU = 3 };
 

@@ -11,6 +11,16 @@
 // Occupancy (2-3 workgroups per CU) overlaps one workgroup's staging with another's MFMAs; one barrier pair per stage.
 // With WINO the 3 kw taps of a filter row are replaced by the 4 products of Winograd F(2,3) (see conv_wino.hip): the
 // patch is read as 4 input columns per output PAIR, transformed in registers, and the slab holds U = G g (12 "taps").
+//
+// Input modes (template IN) — the normalisation / resampling passes that used to run between two convolutions of a decoder
+// block now happen while the patch is staged (reference score_unet.py:583-615):
+//   IN = 1  affine on load: the patch holds x*scale[b,c] + shift[b,c] (GroupNorm of the producer's raw output, statistics
+//           finalised into `in_affine` by gn_finalize_kernel); out-of-image pixels stay 0 (zero padding of the NORMALISED map)
+//   IN = 2  bilinear x2 on load (nn.Upsample, align_corners=False): x is the LOW-resolution map [B][H/2][W/2][Cs].  Per stage
+//           the (TH/2+2) x 10 low-res pixels under the patch are loaded (edge-clamped), optionally transformed
+//           act(x*scale + shift + skip) (the pending GroupNorm + skip + time bias + activation of the previous block), parked
+//           in a small LDS region and expanded into the 18-wide patch with PyTorch's 0.25 / 0.75 taps.  The upsampled tensor
+//           (134 MB at the final block of a B=32, 128x128 evaluation) is never written or re-read.
 #include "common.h"
 #include "kernels.h"
 #include "conv_common.h"
@@ -29,7 +39,7 @@ constexpr int PWID = TW + 2;    // patch width (loaded columns)
 __device__ __forceinline__ int swz(int idx, int quad) { return idx * 4 + ((quad + (idx >> 1)) & 3); }
 
 // DB: two LDS stage buffers -> one barrier per stage instead of two, and a stage's LDS stores overlap the other waves' MFMAs.
-template <int FCO, int FPX, bool WINO, bool DB>
+template <int FCO, int FPX, bool WINO, bool DB, int IN>
 __global__ __launch_bounds__(256) void conv3x3_lds_kernel(const ConvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     constexpr int TH = (WINO ? 8 : 4) * FPX;    // tile rows: 4 waves x FPX rows (Winograd: 2*FPX rows per wave)
@@ -40,8 +50,11 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(const ConvParams p) {
     constexpr int PWS = WINO ? PWID + 1 : PWID; // patch row stride in LDS (odd for the Winograd column pairs)
     constexpr int PQ = PH * PWID * 4;           // patch quads loaded per stage
     constexpr int STAGE_QUADS = WQ + PH * PWS * 4;
+    constexpr int LH = TH / 2 + 2, LW = TW / 2 + 2;             // IN == 2: low-resolution pixels under the patch
+    constexpr int LQ = LH * LW * 4;
     f32x4* wl = reinterpret_cast<f32x4*>(smem_raw);            // [tap][co][4 quads]
     f32x4* pt = wl + WQ;                                        // [py][px (stride PWS)][4 quads, rotated]
+    f32x4* const lr0 = reinterpret_cast<f32x4*>(smem_raw) + (DB ? 2 : 1) * STAGE_QUADS;   // IN == 2: [DB ? 2 : 1][LH][LW][4 quads]
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -74,7 +87,9 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(const ConvParams p) {
     // registers while the matrix pipe works; they are written to LDS after the barrier that retires stage cb's reads.
     constexpr int WPT = (WQ + 255) / 256;       // weight quads per thread per stage
     constexpr int PPT = (PQ + 255) / 256;       // patch quads per thread per stage
-    f32x4 rw[WPT], rp[PPT];
+    constexpr int LPT = (LQ + 255) / 256;       // IN == 2: low-res quads per thread per stage
+    const int hl = p.H >> 1, wlo = p.W >> 1;    // IN == 2: low-res extent
+    f32x4 rw[WPT], rp[IN == 2 ? LPT : PPT], rs[IN == 2 ? LPT : 1], sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
     auto stage_load = [&](int cb) {
 #pragma unroll
         for (int u = 0; u < WPT; ++u) {
@@ -85,36 +100,108 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(const ConvParams p) {
             else off = (uint32_t)(((((tap >> 2) * CB + cb) * 4 + (tap & 3)) * p.Cout + co0) * 16 + rem * 4) * 4u;   // [kh][cb][xi][Cout][16]
             rw[u] = buf_load4(wr, q < WQ ? off : 0x80000000u);
         }
+        if (IN != 0 && p.in_affine != nullptr) {             // a thread's quads all share (tid & 3): one scale / shift pair per stage
+            const float* ap = p.in_affine + (((size_t)b * (p.Cs >> 2) + cb * 4 + (tid & 3)) * 2) * 4;
+            sc = *reinterpret_cast<const f32x4*>(ap);
+            sh = *reinterpret_cast<const f32x4*>(ap + 4);
+        }
+        if (IN != 2) {
 #pragma unroll
-        for (int u = 0; u < PPT; ++u) {
-            const int q = tid + 256 * u;
-            const int quad = q & 3, pix = q >> 2;
-            const int py = pix / PWID, px = pix - py * PWID;
-            const int iy = y0 - 1 + py, ix = x0 - 1 + px;
-            const bool ok = (q < PQ) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
-            rp[u] = buf_load4(xr, ok ? (uint32_t)(((b * p.H + iy) * p.W + ix) * p.Cs + cb * 16 + quad * 4) * 4u : 0x80000000u);
+            for (int u = 0; u < PPT; ++u) {
+                const int q = tid + 256 * u;
+                const int quad = q & 3, pix = q >> 2;
+                const int py = pix / PWID, px = pix - py * PWID;
+                const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+                const bool ok = (q < PQ) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+                rp[u] = buf_load4(xr, ok ? (uint32_t)(((b * p.H + iy) * p.W + ix) * p.Cs + cb * 16 + quad * 4) * 4u : 0x80000000u);
+            }
+        } else {
+#pragma unroll
+            for (int u = 0; u < LPT; ++u) {                  // low-res pixel (row r, col c) of the L region, edge-clamped
+                const int q = tid + 256 * u;
+                const int quad = q & 3, pix = q >> 2;
+                const int r = pix / LW, c = pix - r * LW;
+                const int ly = min(max((y0 >> 1) - 1 + r, 0), hl - 1), lx = min(max((x0 >> 1) - 1 + c, 0), wlo - 1);
+                const uint32_t off = q < LQ ? (uint32_t)(((b * hl + ly) * wlo + lx) * p.Cs + cb * 16 + quad * 4) * 4u : 0x80000000u;
+                rp[u] = buf_load4(xr, off);
+                if (p.in_skip != nullptr) rs[u] = buf_load4(make_rsrc(p.in_skip, p.x_bytes), off);
+            }
         }
     };
     f32x4* const wl0 = wl;
     f32x4* const pt0 = pt;
-    auto stage_store = [&](int buf) {
+    auto stage_store_w = [&](int buf) {
         f32x4* wd = wl0 + buf * STAGE_QUADS;
-        f32x4* pd = pt0 + buf * STAGE_QUADS;
 #pragma unroll
         for (int u = 0; u < WPT; ++u) {
             const int q = tid + 256 * u;                       // [tap][co][quad]: rotate the quad by the fragment row (co & 15) >> 1
             if (q < WQ) wd[(q & ~3) + (((q & 3) + (((q >> 2) & 15) >> 1)) & 3)] = rw[u];
         }
+    };
+    auto stage_store_p = [&](int buf) {                        // IN != 2: the patch straight from the load registers
+        f32x4* pd = pt0 + buf * STAGE_QUADS;
 #pragma unroll
         for (int u = 0; u < PPT; ++u) {
             const int q = tid + 256 * u;
             const int pix = q >> 2, py = pix / PWID, px = pix - py * PWID;
-            if (q < PQ) pd[py * PWS * 4 + swz(px, q & 3)] = rp[u];
+            f32x4 v = rp[IN == 2 ? 0 : u];
+            if (IN == 1) {
+                const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+                const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+                v = ok ? v * sc + sh : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+            if (q < PQ) pd[py * PWS * 4 + swz(px, q & 3)] = v;
+        }
+    };
+    auto stage_store_l = [&](int lbuf) {                       // IN == 2: transformed low-res quads -> L region
+        f32x4* ld = lr0 + lbuf * LQ;
+#pragma unroll
+        for (int u = 0; u < LPT; ++u) {
+            const int q = tid + 256 * u;
+            f32x4 v = rp[u];
+            if (p.in_affine != nullptr) v = v * sc + sh;
+            if (p.in_skip != nullptr) v += rs[u];
+            if (p.in_act != SBGM_ACT_NONE) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = sbgm_act(v[e], p.in_act);
+            }
+            if (q < LQ) ld[q] = v;
+        }
+    };
+    auto expand = [&](int lbuf, int buf) {                     // IN == 2: L region -> 18-wide patch, bilinear x2 (align_corners=False)
+        const f32x4* ls = lr0 + lbuf * LQ;
+        f32x4* pd = pt0 + buf * STAGE_QUADS;
+#pragma unroll 1                                             // one quad at a time: 4 reads + blend stay out of the accumulators' way
+        for (int u = 0; u < PPT; ++u) {
+            const int q = tid + 256 * u;
+            const int quad = q & 3, pix = q >> 2;
+            const int py = pix / PWID, px = pix - py * PWID;
+            const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+            const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+            // rows a = py >> 1, b = a + 1 of the L region (y0, x0 are even); weights as PyTorch: even output row 0.25 / 0.75
+            // (row 0: 0 / 1), odd output row 0.75 / 0.25
+            const int ra = py >> 1, ca = px >> 1;
+            const float wya = (py & 1) ? (iy == 0 ? 0.f : 0.25f) : 0.75f, wyb = 1.f - wya;
+            const float wxa = (px & 1) ? (ix == 0 ? 0.f : 0.25f) : 0.75f, wxb = 1.f - wxa;
+            if (q < PQ) {
+                const f32x4 v00 = ls[(ra * LW + ca) * 4 + quad], v01 = ls[(ra * LW + ca + 1) * 4 + quad];
+                const f32x4 v10 = ls[((ra + 1) * LW + ca) * 4 + quad], v11 = ls[((ra + 1) * LW + ca + 1) * 4 + quad];
+                const f32x4 o = wya * (wxa * v00 + wxb * v01) + wyb * (wxa * v10 + wxb * v11);
+                pd[py * PWS * 4 + swz(px, quad)] = ok ? o : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
         }
     };
     stage_load(0);
-    stage_store(0);
-    if (DB && CB > 1) stage_load(1);
+    stage_store_w(0);
+    if (IN != 2) {
+        stage_store_p(0);
+        if (DB && CB > 1) stage_load(1);
+    } else {
+        stage_store_l(0);
+        __syncthreads();
+        expand(0, 0);
+        if (DB && CB > 1) { stage_load(1); stage_store_l(1); }
+    }
     for (int cb = 0; cb < CB; ++cb) {
         if (!DB) {
             if (cb + 1 < CB) stage_load(cb + 1);
@@ -122,7 +209,9 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(const ConvParams p) {
         } else {
             __syncthreads();                     // stage cb is visible; every wave has finished stage cb-1 (the other buffer)
             if (cb + 1 < CB) {
-                stage_store((cb + 1) & 1);
+                stage_store_w((cb + 1) & 1);
+                if (IN != 2) stage_store_p((cb + 1) & 1);
+                else expand((cb + 1) & 1, (cb + 1) & 1);     // L[(cb+1)&1] was parked before the barrier
                 if (cb + 2 < CB) stage_load(cb + 2);
             }
             wl = wl0 + (cb & 1) * STAGE_QUADS;
@@ -178,8 +267,15 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(const ConvParams p) {
             }
         }
         if (!DB) {
+            if (IN == 2 && cb + 1 < CB) stage_store_l(0);    // the L region was last read before this stage's first barrier
             __syncthreads();                     // every wave is done reading this stage
-            if (cb + 1 < CB) stage_store(0);
+            if (cb + 1 < CB) {
+                stage_store_w(0);
+                if (IN != 2) stage_store_p(0);
+                else expand(0, 0);
+            }
+        } else if (IN == 2 && cb + 2 < CB) {
+            stage_store_l(cb & 1);               // stage cb+2's low-res quads; L[cb & 1] was expanded before this stage's barrier
         }
     }
 
@@ -320,6 +416,15 @@ int sbgm_conv_lds_gn_chunks(const ConvParams& p, const ConvTile& cfg) {
     return chunks <= 64 ? chunks : 0;
 }
 
+// dynamic LDS of one workgroup: the stage buffer(s) plus, with upsample-on-load, the low-resolution parking region(s)
+size_t sbgm_conv_lds_bytes(const ConvTile& cfg, int in_mode) {
+    const int TH = 4 * (cfg.wino ? 2 * cfg.fpx : cfg.fpx);
+    const int nbuf = cfg.lds == 2 ? 2 : 1;
+    size_t quads = ((size_t)(cfg.wino ? 12 : 9) * 16 * cfg.fco * 4 + (size_t)(TH + 2) * (cfg.wino ? 19 : 18) * 4) * nbuf;
+    if (in_mode == 2) quads += (size_t)(TH / 2 + 2) * 10 * 4 * nbuf;
+    return quads * 16;
+}
+
 // cfg: fco in {1,2,4}; fpx = tile rows per wave (direct: 1,2,4 -> tile 4/8/16 rows; Winograd: rows per wave = 2*fpx);
 // cfg.wino selects the Winograd slab (p.wp must then be the Winograd pack).  W must be a multiple of 16.
 int sbgm_launch_conv_lds(ConvParams p, const ConvTile& cfg, hipStream_t st) {
@@ -328,34 +433,43 @@ int sbgm_launch_conv_lds(ConvParams p, const ConvTile& cfg, hipStream_t st) {
     SBGM_CHECK(p.act == SBGM_ACT_NONE || p.act == SBGM_ACT_RELU || p.act == SBGM_ACT_GELU, "conv_lds: act=%d does not fuse", p.act);
     SBGM_CHECK((size_t)p.B * p.H * p.W * p.Cs * 4 < (1ull << 31), "conv_lds: input tensor exceeds 2 GiB buffer window");
     SBGM_CHECK(p.proj_w == nullptr || (p.Cout == 16 * cfg.fco && p.proj_out != nullptr), "conv_lds: tap projection needs one co tile");
+    SBGM_CHECK(p.in_mode >= 0 && p.in_mode <= 2, "conv_lds: in_mode=%d", p.in_mode);
+    SBGM_CHECK(p.in_mode == 0 || cfg.wino, "conv_lds: the fused input modes are instantiated for the Winograd tiles only");
+    SBGM_CHECK(p.in_mode != 1 || p.in_affine != nullptr, "conv_lds: in_mode 1 needs in_affine");
+    SBGM_CHECK(p.in_mode == 2 || (p.in_skip == nullptr && p.in_act == SBGM_ACT_NONE), "conv_lds: skip / activation on load need in_mode 2");
+    SBGM_CHECK(p.in_mode != 2 || (p.H % 2 == 0 && p.W % 2 == 0), "conv_lds: upsample-on-load needs even H, W");
     if (p.gn_stats && sbgm_conv_lds_gn_chunks(p, cfg) == 0) p.gn_stats = nullptr;      // this tile cannot produce them
     p.OH = p.H; p.OW = p.W;
     p.M = p.B * p.H * p.W;
     p.cb_per_tap = p.Cs / 16;
     p.nsteps = 9 * p.cb_per_tap;
-    p.x_bytes = (uint32_t)((size_t)p.B * p.H * p.W * p.Cs * 4);
+    p.x_bytes = (uint32_t)((size_t)p.B * p.H * p.W * p.Cs * 4 / (p.in_mode == 2 ? 4 : 1));
     p.w_bytes = (uint32_t)((cfg.wino ? sbgm_wino_packed_floats(p.Cout, p.Cs) : (size_t)9 * p.cb_per_tap * p.Cout * 16) * 4);
     const int rows_per_wave = cfg.wino ? 2 * cfg.fpx : cfg.fpx;
     const int TH = 4 * rows_per_wave;
     const int tiles = (p.W / 16) * ((p.H + TH - 1) / TH) * p.B * (p.Cout / (16 * cfg.fco));
     const int ntap = cfg.wino ? 12 : 9;
     const bool db = cfg.lds == 2;                       // double-buffered stages
-    const size_t lds = ((size_t)ntap * 16 * cfg.fco * 4 + (size_t)(TH + 2) * (cfg.wino ? 19 : 18) * 4) * 16 * (db ? 2 : 1);
+    const size_t lds = sbgm_conv_lds_bytes(cfg, p.in_mode);
     SBGM_CHECK(lds <= 160 * 1024, "conv_lds: tile needs %zu bytes of LDS", lds);
+    (void)ntap;
     int rc = 1;
-#define SBGM_L2(FC, FP, WN, DBV)                                                                            \
-    if (cfg.fco == FC && cfg.fpx == FP && (cfg.wino != 0) == WN && db == DBV) {                               \
+#define SBGM_L3(FC, FP, WN, DBV, INV)                                                                        \
+    if (cfg.fco == FC && cfg.fpx == FP && (cfg.wino != 0) == WN && db == DBV && p.in_mode == INV) {           \
         if (lds > 64 * 1024)                                                                                  \
-            SBGM_HIP(hipFuncSetAttribute((const void*)conv3x3_lds_kernel<FC, FP, WN, DBV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((conv3x3_lds_kernel<FC, FP, WN, DBV>), dim3(tiles), dim3(256), lds, st, p);      \
+            SBGM_HIP(hipFuncSetAttribute((const void*)conv3x3_lds_kernel<FC, FP, WN, DBV, INV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+        hipLaunchKernelGGL((conv3x3_lds_kernel<FC, FP, WN, DBV, INV>), dim3(tiles), dim3(256), lds, st, p); \
         rc = 0;                                                                                              \
     }
-#define SBGM_L(FC, FP, WN) SBGM_L2(FC, FP, WN, false) SBGM_L2(FC, FP, WN, true)
+#define SBGM_L(FC, FP, WN) SBGM_L3(FC, FP, WN, false, 0) SBGM_L3(FC, FP, WN, true, 0)
+#define SBGM_LF(FC, FP) SBGM_L3(FC, FP, true, false, 1) SBGM_L3(FC, FP, true, true, 1) SBGM_L3(FC, FP, true, false, 2) SBGM_L3(FC, FP, true, true, 2)
     SBGM_L(4, 1, false) SBGM_L(4, 2, false) SBGM_L(4, 4, false) SBGM_L(2, 2, false) SBGM_L(2, 4, false) SBGM_L(2, 1, false)
     SBGM_L(4, 1, true) SBGM_L(4, 2, true) SBGM_L(2, 1, true) SBGM_L(2, 2, true) SBGM_L(1, 1, true) SBGM_L(1, 2, true)
+    SBGM_LF(4, 1) SBGM_LF(4, 2) SBGM_LF(2, 1) SBGM_LF(2, 2) SBGM_LF(1, 1) SBGM_LF(1, 2)
+#undef SBGM_LF
 #undef SBGM_L
-#undef SBGM_L2
-    SBGM_CHECK(rc == 0, "conv_lds: no kernel for tile fco=%d fpx=%d wino=%d", cfg.fco, cfg.fpx, cfg.wino);
+#undef SBGM_L3
+    SBGM_CHECK(rc == 0, "conv_lds: no kernel for tile fco=%d fpx=%d wino=%d in_mode=%d", cfg.fco, cfg.fpx, cfg.wino, p.in_mode);
     SBGM_LAUNCH_CHECK();
     return 0;
 }

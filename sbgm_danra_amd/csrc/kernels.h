@@ -35,6 +35,13 @@ struct ConvParams {
                           // 8 taps x 2 channels (weights packed with cs = 2) instead of 4 taps x 4 slots, halving the MFMA work
     int in_dil;           // 1, or 2: read the input through a zero-inserted grid (data-gradient of a stride-2 conv)
     int out_h, out_w;     // explicit output size (required with in_dil == 2), else 0
+    // conv_lds only — what happens to the input while the halo patch is staged (conv_lds.hip, "Input modes"):
+    int in_mode;          // 0 plain; 1 affine on load (x*scale + shift per (sample, channel), zero padding kept); 2 bilinear x2 on
+                          // load: x is the LOW-resolution map [B][H/2][W/2][Cs] (H, W stay the convolution's own size), optionally
+                          // transformed act(x*scale + shift + skip) before the interpolation
+    const float* in_affine;  // [B][Cs/4][2][4] (scale quad, shift quad) from sbgm_launch_gn_finalize, or null
+    const float* in_skip;    // mode 2: [B][H/2][W/2][Cs] added before the activation, or null
+    int in_act;              // mode 2: SBGM_ACT_* applied to the low-res value
     // filled by sbgm_launch_conv:
     int OH, OW, M, cb_per_tap, nsteps, steps_per_split, n_px_tiles, n_co_tiles;
     uint32_t x_bytes, w_bytes;
@@ -63,6 +70,7 @@ int sbgm_launch_conv_wino(ConvParams p, const ConvTile& cfg, hipStream_t st);   
 
 // ---- conv_lds.hip: 3x3 stride-1 pad-1 convolution with LDS-staged halo patch + weight slab (direct or Winograd) -----------
 int sbgm_launch_conv_lds(ConvParams p, const ConvTile& cfg, hipStream_t st);
+size_t sbgm_conv_lds_bytes(const ConvTile& cfg, int in_mode);
 // chunks per sample the launch above writes into p.gn_stats for this tile, or 0 if that tile cannot produce them
 int sbgm_conv_lds_gn_chunks(const ConvParams& p, const ConvTile& cfg);
 
@@ -122,6 +130,12 @@ int sbgm_launch_groupnorm_apply(const float* x, float* y, const float* gamma, co
 int sbgm_launch_groupnorm(const float* x, float* y, const float* gamma, const float* beta, const float* skip,
                           const float* tbias, int act, int B, int HW, int C, int G, float eps, double* stats_ws,
                           hipStream_t st, float* mr_out = nullptr);   // mr_out: [B][G][2] (mean, rstd) kept for backward
+// GroupNorm statistics (chunk partials as written by gn_partial / the conv_lds epilogue) -> per-(sample, channel) affine
+// out[b][c/4][0][4] = rstd*gamma, out[b][c/4][1][4] = beta - mean*rstd*gamma (+ tbias[b][c]): what conv_lds applies on load
+int sbgm_launch_gn_finalize(const double* stats, int chunks, const float* gamma, const float* beta, const float* tbias, float* out,
+                            int B, int HW, int C, int G, float eps, hipStream_t st);
+// first half of sbgm_launch_groupnorm only: the chunk partials; returns the chunk count through *chunks
+int sbgm_launch_gn_partial(const float* x, double* stats_ws, int B, int HW, int C, int G, int* chunks, hipStream_t st);
 int sbgm_launch_layernorm(const float* x, float* y, const float* gamma, const float* beta, int M, int C, float eps,
                           hipStream_t st);
 // train-mode BatchNorm2d: batch statistics over (B,H,W), running-stat update, optional residual + ReLU

@@ -358,7 +358,7 @@ int sbgm_launch_layernorm(const float* x, float* y, const float* gamma, const fl
 // first half of a train-mode BatchNorm: per-channel fp64 sums (x, x^2) of THIS process's batch into stats_ws[2C]
 int sbgm_launch_batchnorm_stats(const float* x, int B, int HW, int C, double* stats_ws, hipStream_t st) {
     SBGM_CHECK(C % 4 == 0 && C <= 1024, "batchnorm: C=%d unsupported", C);
-    if (!sbgm_scratch_prezeroed) SBGM_HIP(hipMemsetAsync(stats_ws, 0, sizeof(double) * 2 * (size_t)C, st));
+    if (!sbgm_scratch_prezeroed) { if (sbgm_zero_async(stats_ws, sizeof(double) * 2 * (size_t)C, st)) return 1; }
     // treat the batch as one long pixel axis: [B*HW][C]
     const int n = B * HW;
     const int lanes_px = std::max(1, NORM_THREADS / (C / 4));

@@ -293,6 +293,26 @@ inline int stream_blocks(size_t work_items) { return (int)std::min<size_t>((work
 
 }  // namespace
 
+namespace {
+__global__ __launch_bounds__(256) void zero_kernel(uint32_t* __restrict__ p, size_t n_dwords) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_dwords; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+__global__ __launch_bounds__(256) void zero4_kernel(i32x4* __restrict__ p, size_t n_quads) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_quads; i += (size_t)gridDim.x * blockDim.x) p[i] = i32x4{0, 0, 0, 0};
+}
+}  // namespace
+
+int sbgm_zero_async(void* p, size_t bytes, hipStream_t st) {
+    if (bytes == 0) return 0;
+    SBGM_CHECK(p != nullptr && bytes % 4 == 0 && (reinterpret_cast<uintptr_t>(p) & 3) == 0, "zero_async: %zu bytes at %p (need 4-byte granularity)", bytes, p);
+    if (bytes % 16 == 0 && (reinterpret_cast<uintptr_t>(p) & 15) == 0)
+        hipLaunchKernelGGL(zero4_kernel, dim3(stream_blocks(bytes / 16)), dim3(256), 0, st, static_cast<i32x4*>(p), bytes / 16);
+    else
+        hipLaunchKernelGGL(zero_kernel, dim3(stream_blocks(bytes / 4)), dim3(256), 0, st, static_cast<uint32_t*>(p), bytes / 4);
+    SBGM_LAUNCH_CHECK();
+    return 0;
+}
+
 int sbgm_launch_pack_input(const PackSrc& src, float* dst, int B, int H, int W, int Cs, hipStream_t st) {
     int ctot = 0;
     for (int i = 0; i < src.n; ++i) ctot += src.ch[i];

@@ -173,7 +173,7 @@ int sbgm_launch_langevin(float* x, const float* score, const float* z, float snr
                          SamplerState* state, unsigned long long draw_index, unsigned long long seed, int B,
                          size_t per_sample, hipStream_t st, NoiseMap nm) {
     SBGM_CHECK(per_sample % 4 == 0, "langevin: per-sample element count must be a multiple of 4");
-    SBGM_HIP(hipMemsetAsync(sumsq_ws, 0, sizeof(double) * B, st));
+    { if (sbgm_zero_async(sumsq_ws, sizeof(double) * B, st)) return 1; }
     const int bx = (int)std::min<size_t>((per_sample / 4 + 255) / 256, 64);
     hipLaunchKernelGGL(sumsq_kernel, dim3(bx, B), dim3(256), 0, st, score, sumsq_ws, per_sample / 4);
     SBGM_LAUNCH_CHECK();

@@ -461,6 +461,10 @@ def loss_fn(model, x, marginal_prob_std, t_eps=1e-3, device=None, y=None, cond_i
         if t_in.numel() != B or z_in.shape != xc.shape:
             raise ValueError(f"noise=(t, z) must have shapes [{B}] and {tuple(xc.shape)}")
     capturing = torch.cuda.is_current_stream_capturing()
+    if noise is None and not capturing:
+        _loss_rng_state(dev)                      # created eagerly (warm-up steps): a host->device copy is illegal during capture
+    if noise is None and capturing and dev not in _LOSS_RNG:
+        raise RuntimeError("loss_fn: run one eager (warm-up) step before capturing it into a graph")
     rng = _loss_rng_state(dev) if (noise is None and capturing) else None
     seed = 0
     if noise is None and not capturing:

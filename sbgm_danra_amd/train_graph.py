@@ -102,6 +102,7 @@ class GradArena:
 
 
 _ACTIVE_ARENA = [None]
+_USE_ARENA = [True]             # debugging switch: False = every gradient in a fresh tensor (the pre-arena behaviour)
 
 
 def arena_for(net, create=True):
@@ -677,7 +678,7 @@ def forward_train(net, x, t, y, cond, lsm, topo):
     _NBT.clear()
     _zero_reset(x.device)
     arena = None
-    if all(p.grad is None for p in net.parameters()):      # fresh step: gradients go straight into the model's flat arena
+    if _USE_ARENA[0] and all(p.grad is None for p in net.parameters()):      # fresh step: gradients go straight into the model's flat arena
         arena = arena_for(net)
         arena.begin_step()
     _ACTIVE_ARENA[0] = arena

@@ -4,7 +4,8 @@ test_gpu_backward.py):
   C1  64x64, B=1, C_in=1 (no conditions), Euler-Maruyama: 5 injected-noise steps vs the oracle, then 50 steps
       (determinism, hipGraph replay == eager launches bit for bit)                      reference score_sampling.py:63-127
   C3  128x128, 4 LR conditions (C_in=5), B=8: one training step — loss and EVERY parameter gradient vs CPU autograd of the
-      oracle with injected (t, z); the worst max-rel per parameter group is printed    reference training.py:323-410
+      oracle (float64 evaluation as truth, fp32 evaluation beside it) with injected (t, z); the worst max-rel per parameter
+      group is printed                                                                 reference training.py:323-410
   C5  589x789 domain, 256x256 tiles, halo 32, predictor-corrector: end to end (shape, finite, deterministic, independent of
       how the tiles are batched) + one tile-sized network evaluation vs the oracle     (tiler: no reference counterpart)
 
@@ -69,40 +70,52 @@ def _group(name):
 
 
 def test_config3_training_step_128x128_batch8_all_gradients():
+    """Truth = the oracle evaluated in float64 (same algorithm, same fp32 weights / inputs / (t, z)).  Train-mode BatchNorm makes
+    some encoder gradients ill-conditioned at this shape: the reference's own fp32 CPU arithmetic is up to ~1e-2 away from the
+    float64 result there (printed), so fp32-vs-fp32 cannot separate rounding noise from an implementation error, float64 can.
+    Asserted: native vs float64 <= 1e-4 for EVERY parameter, and the native error <= the fp32 oracle's own error + 1e-4."""
+    import copy
     import sbgm_danra_amd as S
     from oracle import torch_ref as O
     torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
     ora, net, _ = build_pair(4)
     ora.train(), net.train()
+    ora64 = copy.deepcopy(ora).double()
     g = torch.Generator().manual_seed(333)
     B = 8
     x, cond = torch.randn(B, 1, 128, 128, generator=g), torch.randn(B, 4, 128, 128, generator=g)
     t, z = torch.rand(B, generator=g) * 0.999 + 1e-3, torch.randn(B, 1, 128, 128, generator=g)
     lo = O.loss_fn(ora, x, O.marginal_prob_std_fn, cond_img=cond, noise=(t, z))
     lo.backward()
+    l64 = O.loss_fn(ora64, x.double(), O.marginal_prob_std_fn, cond_img=cond.double(), noise=(t, z.double()))
+    l64.backward()
     ln = S.loss_fn(net, x.cuda(), S.marginal_prob_std_fn, cond_img=cond.cuda(), noise=(t.cuda(), z.cuda()))
     ln.backward()
-    loss_err = abs(float(ln.detach()) / float(lo.detach()) - 1)
-    po, pn = dict(ora.named_parameters()), dict(net.named_parameters())
-    errs, groups = {}, {}
-    for k, p in po.items():
+    loss_err = abs(float(ln.detach()) / float(l64.detach()) - 1)
+    po, p64, pn = dict(ora.named_parameters()), dict(ora64.named_parameters()), dict(net.named_parameters())
+    errs, ref_errs, groups = {}, {}, {}
+    for k, p in p64.items():
         if p.grad is None:
             assert pn[k].grad is None, k
             continue
-        errs[k] = maxrel(pn[k].grad.cpu(), p.grad)
+        errs[k] = maxrel(pn[k].grad.cpu().double(), p.grad)
+        ref_errs[k] = maxrel(po[k].grad.double(), p.grad)
         groups[_group(k)] = max(groups.get(_group(k), 0.0), errs[k])
     worst = sorted(errs.items(), key=lambda kv: -kv[1])[:8]
-    print(f"C3 loss rel err {loss_err:.2e}; worst gradients: " + ", ".join(f"{k}={v:.2e}" for k, v in worst))
-    print("C3 worst max-rel per parameter group: " + ", ".join(f"{k}={v:.1e}" for k, v in sorted(groups.items())))
-    _record("c3", {"loss_rel_err": loss_err, "worst": worst, "groups": groups, "n_params": len(errs)})
+    worst_ref = sorted(ref_errs.items(), key=lambda kv: -kv[1])[:4]
+    print(f"C3 loss rel err vs float64 {loss_err:.2e}; worst native gradients vs float64: " + ", ".join(f"{k}={v:.2e}" for k, v in worst))
+    print("C3 fp32 CPU oracle vs float64 (the reference's own rounding noise): " + ", ".join(f"{k}={v:.2e}" for k, v in worst_ref))
+    print("C3 worst native max-rel per parameter group: " + ", ".join(f"{k}={v:.1e}" for k, v in sorted(groups.items())))
+    _record("c3", {"loss_rel_err": loss_err, "worst": worst, "worst_fp32_oracle": worst_ref, "groups": groups, "n_params": len(errs), "all": errs})
     assert loss_err < 1e-5
     assert len(errs) >= 160 and worst[0][1] < 1e-4, worst
+    assert all(errs[k] <= ref_errs[k] + 1e-4 for k in errs)
     # the gradients of the step live in the model's flat arena (what the data-parallel all-reduce exchanges)
     from sbgm_danra_amd.train_graph import arena_for
     arena = arena_for(net, create=False)
     assert arena is not None and all(pn[k].grad.data_ptr() == arena.grad_of(pn[k]).data_ptr() for k in errs)
-    so, sn = ora.state_dict(), net.state_dict()
-    assert max(maxrel(sn[k].cpu(), so[k]) for k in so if "running_" in k) < 1e-4
+    so, sn = ora64.state_dict(), net.state_dict()
+    assert max(maxrel(sn[k].cpu().double(), so[k]) for k in so if "running_" in k) < 1e-4
 
 
 def test_config5_full_domain_589x789_end_to_end():

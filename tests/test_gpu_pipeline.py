@@ -200,7 +200,7 @@ def test_training_step_as_hip_graph(cfg_path):
     assert not torch.equal(before, model.encoder.conv2.weight)
     b = pipe.train_batches(dl, epochs=2, current_epoch=2, verbose=False)
     assert np.isfinite(b) and int(model.encoder.bn1.num_batches_tracked) == 6 and len(pipe._graphs) == 1
-    assert all(p.grad is not None and torch.isfinite(p.grad).all() for k, p in model.named_parameters()
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() and float(p.grad.abs().max()) < 1e8 for k, p in model.named_parameters()
                if not k.startswith("decoder.final_layer.time_"))
 
 
