@@ -47,7 +47,7 @@ struct BlockW { ConvW c1, c2, ds; BNW bn1, bn2, dsbn; bool has_ds; int cin, cout
 struct DecW { ConvW up, conv; Param *n1g, *n1b, *n2g, *n2b, *freq, *tpw, *tpb; AttnW attn; bool has_attn; int cin, cout; };
 
 struct ConvOpKey {
-    int kh, kw, s, p, B, H, W, Cs, Cout, proj;
+    int kh, kw, s, p, B, H, W, Cs, Cout, proj, in_mode;
     bool operator<(const ConvOpKey& o) const { return std::memcmp(this, &o, sizeof(*this)) < 0; }
 };
 
@@ -81,7 +81,7 @@ struct sbgm_model {
     std::map<ConvOpKey, ConvTile> tuned;
     ConvTile last_tile{};                   // tile of the most recent conv() (tells the caller whether GroupNorm statistics were fused)
     bool tuning = false;
-    struct ConvRec { ConvGeom g; int B, H, W, Cs, Cout, M, nsteps; ConvTile t; double flops; hipEvent_t e0, e1; float ms; int c_real; };
+    struct ConvRec { ConvGeom g; int B, H, W, Cs, Cout, M, nsteps; ConvTile t; double flops; hipEvent_t e0, e1; float ms; int c_real; int in_mode; };
     std::vector<ConvRec>* prof = nullptr;   // when set, conv() brackets every launch with events
     static constexpr int PROF_REPS = 4;
     hipStream_t graph_stream = nullptr;     // private capture stream (the caller's may be the legacy default stream)
@@ -334,9 +334,10 @@ int sbgm_model::fold_bn(hipStream_t st) {
 // small-spatial layers whose M*Cout is too small even with small tiles.
 ConvTile sbgm_model::pick_tile(const ConvGeom& g, const ConvParams& p) {
     const int OH = (p.H + 2 * g.pad - g.kh) / g.stride + 1, OW = (p.W + 2 * g.pad - g.kw) / g.stride + 1;
-    ConvOpKey key{g.kh, g.kw, g.stride, g.pad, p.B, p.H, p.W, p.Cs, p.Cout, p.proj_w != nullptr};
+    ConvOpKey key{g.kh, g.kw, g.stride, g.pad, p.B, p.H, p.W, p.Cs, p.Cout, p.proj_w != nullptr, p.in_mode};
     auto it = tuned.find(key);
     if (it != tuned.end()) return it->second;
+    if (p.in_mode != 0) return ConvTile{p.Cout % 64 == 0 ? 4 : 2, 1, 1, 1, 1, 1};     // fused input modes: LDS-staged Winograd tiles only
     const bool wino_ok = p.wp_wino != nullptr && g.kh == 3 && g.kw == 3 && g.stride == 1 && g.pad == 1 && p.W % 2 == 0;
     if (wino_ok) {                                    // Winograd F(2,3): 1.5x fewer MFMAs; pick waves-per-tile to fill the chip
         const int Mp = p.B * OH * OW / 2, ns = 3 * (p.Cs / 16);
@@ -380,6 +381,7 @@ int sbgm_tune_conv(const ConvGeom& g, const ConvParams& p, float* partial, size_
     std::vector<ConvTile> cands;
     const int tiles[6][2] = {{4, 4}, {4, 2}, {4, 1}, {2, 4}, {2, 2}, {2, 1}};
     for (auto& t : tiles) {
+        if (p.in_mode != 0) break;                    // the fused input modes exist in the LDS-staged Winograd kernel only
         if (p.Cout % (16 * t[0])) continue;
         if (p.proj_w && 16 * t[0] != p.Cout) continue;
         const long ntile = (long)(((size_t)p.B * OH * OW + 16 * t[1] - 1) / (16 * t[1])) * (p.Cout / (16 * t[0]));
@@ -393,7 +395,7 @@ int sbgm_tune_conv(const ConvGeom& g, const ConvParams& p, float* partial, size_
     }
     const bool s1 = g.kh == 3 && g.kw == 3 && g.stride == 1 && g.pad == 1 && p.in_dil <= 1 &&
                     (p.out_h == 0 || (p.out_h == p.H && p.out_w == p.W));
-    if (p.wp_wino != nullptr && s1 && p.W % 2 == 0) {
+    if (p.wp_wino != nullptr && s1 && p.W % 2 == 0 && p.in_mode == 0) {
         const int wt[4][2] = {{4, 1}, {2, 2}, {2, 1}, {4, 2}};
         const int nsw = 3 * (p.Cs / 16);
         for (auto& t : wt) {
@@ -411,6 +413,7 @@ int sbgm_tune_conv(const ConvGeom& g, const ConvParams& p, float* partial, size_
             return ((size_t)(wino ? 12 : 9) * 16 * fco * 4 + (size_t)(4 * rows_per_wave + 2) * (wino ? 19 : 18) * 4) * 16;
         };
         for (auto& t : dt) {
+            if (p.in_mode != 0) break;
             if (p.Cout % (16 * t[0]) || (p.proj_w && 16 * t[0] != p.Cout)) continue;
             cands.push_back(ConvTile{t[0], t[1], 1, 1, 0, 1});
             if (2 * lds_bytes(t[0], t[1], false) <= 160 * 1024) cands.push_back(ConvTile{t[0], t[1], 1, 1, 0, 2});   // double-buffered
@@ -419,8 +422,8 @@ int sbgm_tune_conv(const ConvGeom& g, const ConvParams& p, float* partial, size_
         if (p.wp_wino)
             for (auto& t : wt2) {
                 if (p.Cout % (16 * t[0]) || (p.proj_w && 16 * t[0] != p.Cout)) continue;
-                cands.push_back(ConvTile{t[0], t[1], 1, 1, 1, 1});
-                if (2 * lds_bytes(t[0], 2 * t[1], true) <= 160 * 1024) cands.push_back(ConvTile{t[0], t[1], 1, 1, 1, 2});
+                if (sbgm_conv_lds_bytes(ConvTile{t[0], t[1], 1, 1, 1, 1}, p.in_mode) <= 160 * 1024) cands.push_back(ConvTile{t[0], t[1], 1, 1, 1, 1});
+                if (sbgm_conv_lds_bytes(ConvTile{t[0], t[1], 1, 1, 1, 2}, p.in_mode) <= 160 * 1024) cands.push_back(ConvTile{t[0], t[1], 1, 1, 1, 2});
             }
     }
     hipEvent_t e0, e1;
@@ -471,7 +474,7 @@ int sbgm_model::conv(const ConvGeom& g, ConvParams p, hipStream_t st) {
     const size_t mc = (size_t)p.B * OH * OW * p.Cout;
     if (tuning) {
         // time every candidate on this op, keep the fastest
-        ConvOpKey key{g.kh, g.kw, g.stride, g.pad, p.B, p.H, p.W, p.Cs, p.Cout, p.proj_w != nullptr};
+        ConvOpKey key{g.kh, g.kw, g.stride, g.pad, p.B, p.H, p.W, p.Cs, p.Cout, p.proj_w != nullptr, p.in_mode};
         if (tuned.find(key) == tuned.end()) {
             ConvTile best_t = pick_tile(g, p);
             if (sbgm_tune_conv(g, p, partial, PARTIAL_FLOATS, st, &best_t)) return 1;
@@ -482,7 +485,7 @@ int sbgm_model::conv(const ConvGeom& g, ConvParams p, hipStream_t st) {
     if (ct.splits > 1 && mc * ct.splits > PARTIAL_FLOATS) ct.splits = (int)std::max<size_t>(1, PARTIAL_FLOATS / mc);
     last_tile = ct;
     if (!prof) return launch_any(g, p, ct, st);
-    ConvRec r{g, p.B, p.H, p.W, p.Cs, p.Cout, p.B * OH * OW, sbgm_conv_nsteps(g.kh, g.kw, p.c_real == 2 ? 2 : p.Cs), ct, 0.0, nullptr, nullptr, 0.f, p.c_real};
+    ConvRec r{g, p.B, p.H, p.W, p.Cs, p.Cout, p.B * OH * OW, sbgm_conv_nsteps(g.kh, g.kw, p.c_real == 2 ? 2 : p.Cs), ct, 0.0, nullptr, nullptr, 0.f, p.c_real, p.in_mode};
     // algorithmic FLOPs: 2 * M * Cout * (KH*KW*Cin_real); Cs may be padded (only the stem conv), count real K there
     const int cin_real = (g.kh == 8 && p.Cs <= 16) ? cin_total : p.Cs;
     r.flops = 2.0 * r.M * p.Cout * (double)(g.kh * g.kw * cin_real);
@@ -648,57 +651,102 @@ int sbgm_model::forward(const float* x, const float* t, const int64_t* y, const 
     }
 
     // ---- decoder ------------------------------------------------------------------------------------------------------
+    // Fused path (default): no GroupNorm-apply or upsample pass between the convolutions of a block.  conv_up reads the
+    // low-resolution map and interpolates while staging (in_mode 2, with the PREVIOUS block's pending GroupNorm + skip + time
+    // bias + activation applied to the low-res pixels), `conv` reads conv_up's raw output through norm1's affine (in_mode 1);
+    // the statistics come out of the producing convolution's epilogue and one tiny finalize launch turns them into the
+    // per-(sample, channel) scale / shift.  A block whose output feeds attention, and maps narrower than 16 pixels (wave-level
+    // kernels), keep the separate passes.  SBGM_NO_FUSED_DECODER=1 forces the separate passes everywhere.
     const int G_of = cfg.gn_groups;
     auto groups = [&](int c) { return cfg.decoder_norm == SBGM_NORM_GROUP ? std::max(1, std::min(G_of, c)) : c; };
+    static const bool fused_ok = getenv("SBGM_NO_FUSED_DECODER") == nullptr && getenv("SBGM_NO_LDS_CONV") == nullptr && getenv("SBGM_NO_WINOGRAD") == nullptr;
+    auto can_fuse = [&](const ConvW& cw, int c_in, int w_out) {
+        return fused_ok && !cfg.decoder_transpose && w_out % 16 == 0 && c_in % 16 == 0 && cw.w->dev_wino != nullptr;
+    };
+    struct Pending { const float* raw; const float* affine; const float* skip; int act; bool live; } pend{nullptr, nullptr, nullptr, SBGM_ACT_NONE, false};
+    // statistics of `t` [B][hw][c] for its GroupNorm: from the convolution epilogue (chunks > 0) or a separate partial pass
+    auto ensure_stats = [&](const float* t, int hw, int c, int& chunks) -> int {
+        if (chunks > 0) return 0;
+        return sbgm_launch_gn_partial(t, stats, B, hw, c, groups(c), &chunks, st);
+    };
+    // conv_up of a block: input `in` [B][ch][cw_][ci] (or the pending raw map), output raw [B][2ch][2cw_][ci] (+ bias)
+    auto conv_up = [&](const ConvW& cw, const float* in, int ci, int oh, int ow, ConvParams& p, float* out_raw) -> int {
+        p = ConvParams{};
+        p.wp = cw.w->dev; p.wp_wino = cw.w->dev_wino; p.out = out_raw; p.bias = cw.b->dev; p.B = B; p.H = oh; p.W = ow; p.Cs = ci; p.Cout = ci;
+        if (can_fuse(cw, ci, ow)) {
+            p.in_mode = 2;
+            p.x = pend.live ? pend.raw : in;
+            if (pend.live) { p.in_affine = pend.affine; p.in_skip = pend.skip; p.in_act = pend.act; }
+            pend.live = false;
+            return 0;
+        }
+        SBGM_CHECK(!pend.live, "decoder: a pending normalisation reached an unfused convolution");
+        float* up = wsalloc((size_t)B * oh * ow * ci);
+        if (!up) return 1;
+        if (sbgm_launch_upsample2x(in, up, B, oh / 2, ow / 2, ci, st)) return 1;
+        p.x = up;
+        return 0;
+    };
     cur = fm[4]; ch = fh[4]; cw_ = fw[4];
     for (int i = 0; i < 4; ++i) {
         DecW& d = dec[i];
         const int oh = 2 * ch, ow = 2 * cw_;
         SBGM_CHECK(oh == fh[3 - i] && ow == fw[3 - i] && d.cout == FMAP_CH[3 - i], "decoder/skip shape mismatch at block %d", i);
-        float* up = wsalloc((size_t)B * oh * ow * d.cin);
-        if (!up) return 1;
         float* a = wsalloc((size_t)B * oh * ow * d.cin);
         if (!a) return 1;
         ConvParams p{};
         int gn1_chunks = 0;
         if (cfg.decoder_transpose) {                 // ConvTranspose2d: 1x1 conv to 4*cin phase-major channels, then depth -> space
+            float* up = wsalloc((size_t)B * oh * ow * d.cin);
+            if (!up) return 1;
             p.x = cur; p.wp = d.up.w->dev; p.out = up; p.bias = d.up.b->dev; p.B = B; p.H = ch; p.W = cw_; p.Cs = d.cin; p.Cout = 4 * d.cin;
             if (conv(ConvGeom{1, 1, 1, 0}, p, st)) return 1;
             if (sbgm_launch_depth_space2(up, a, B, ch, cw_, d.cin, 1, st)) return 1;
-            p = ConvParams{};
-            p.B = B; p.H = oh; p.W = ow; p.Cs = d.cin;
         } else {
-            if (sbgm_launch_upsample2x(cur, up, B, ch, cw_, d.cin, st)) return 1;
-            p.x = up; p.wp = d.up.w->dev; p.wp_wino = d.up.w->dev_wino; p.out = a; p.bias = d.up.b->dev; p.B = B; p.H = oh; p.W = ow; p.Cs = d.cin; p.Cout = d.cin;
+            if (conv_up(d.up, cur, d.cin, oh, ow, p, a)) return 1;
             p.gn_stats = stats; p.gn_groups = groups(d.cin);        // GroupNorm statistics in the epilogue when the LDS kernel runs
             if (conv(ConvGeom{3, 3, 1, 1}, p, st)) return 1;
             gn1_chunks = sbgm_conv_lds_gn_chunks(p, last_tile);
         }
-        if (gn1_chunks > 0) {
-            if (sbgm_launch_groupnorm_apply(a, a, d.n1g ? d.n1g->dev : nullptr, d.n1b ? d.n1b->dev : nullptr, nullptr, nullptr,
-                                            SBGM_ACT_NONE, B, oh * ow, d.cin, groups(d.cin), GN_EPS, stats, gn1_chunks, st)) return 1;
-        } else if (sbgm_launch_groupnorm(a, a, d.n1g ? d.n1g->dev : nullptr, d.n1b ? d.n1b->dev : nullptr, nullptr, nullptr,
-                                         SBGM_ACT_NONE, B, oh * ow, d.cin, groups(d.cin), GN_EPS, stats, st)) return 1;
         float* c2 = wsalloc((size_t)B * oh * ow * d.cout);
         if (!c2) return 1;
+        if (ensure_stats(a, oh * ow, d.cin, gn1_chunks)) return 1;
+        p = ConvParams{};
+        p.B = B; p.H = oh; p.W = ow; p.Cs = d.cin;
         p.x = a; p.wp = d.conv.w->dev; p.wp_wino = d.conv.w->dev_wino; p.out = c2; p.bias = d.conv.b->dev; p.Cout = d.cout;
+        if (can_fuse(d.conv, d.cin, ow)) {           // norm1 applied while `conv` stages its patch
+            float* aff1 = wsalloc((size_t)B * d.cin * 2);
+            if (!aff1) return 1;
+            if (sbgm_launch_gn_finalize(stats, gn1_chunks, d.n1g ? d.n1g->dev : nullptr, d.n1b ? d.n1b->dev : nullptr, nullptr, aff1, B, oh * ow,
+                                        d.cin, groups(d.cin), GN_EPS, st)) return 1;
+            p.in_mode = 1; p.in_affine = aff1;
+        } else if (sbgm_launch_groupnorm_apply(a, a, d.n1g ? d.n1g->dev : nullptr, d.n1b ? d.n1b->dev : nullptr, nullptr, nullptr,
+                                               SBGM_ACT_NONE, B, oh * ow, d.cin, groups(d.cin), GN_EPS, stats, gn1_chunks, st)) return 1;
         p.gn_stats = stats; p.gn_groups = groups(d.cout);
         if (conv(ConvGeom{3, 3, 1, 1}, p, st)) return 1;
-        const int gn2_chunks = sbgm_conv_lds_gn_chunks(p, last_tile);
-        if (gn2_chunks > 0) {
+        int gn2_chunks = sbgm_conv_lds_gn_chunks(p, last_tile);
+        if (ensure_stats(c2, oh * ow, d.cout, gn2_chunks)) return 1;
+        const ConvW& next_up = i < 3 ? dec[i + 1].up : fin_up;
+        if (!d.has_attn && can_fuse(next_up, d.cout, 2 * ow)) {
+            // norm2 + skip + time bias + activation stay pending: the next conv_up applies them to the low-res pixels it loads
+            float* aff2 = wsalloc((size_t)B * d.cout * 2);
+            if (!aff2) return 1;
+            if (sbgm_launch_gn_finalize(stats, gn2_chunks, d.n2g ? d.n2g->dev : nullptr, d.n2b ? d.n2b->dev : nullptr, tb[5 + i], aff2, B, oh * ow,
+                                        d.cout, groups(d.cout), GN_EPS, st)) return 1;
+            pend = Pending{c2, aff2, fm[3 - i], cfg.decoder_activation, true};
+        } else {
             if (sbgm_launch_groupnorm_apply(c2, c2, d.n2g ? d.n2g->dev : nullptr, d.n2b ? d.n2b->dev : nullptr, fm[3 - i], tb[5 + i],
                                             cfg.decoder_activation, B, oh * ow, d.cout, groups(d.cout), GN_EPS, stats, gn2_chunks, st)) return 1;
-        } else if (sbgm_launch_groupnorm(c2, c2, d.n2g ? d.n2g->dev : nullptr, d.n2b ? d.n2b->dev : nullptr, fm[3 - i], tb[5 + i],
-                                         cfg.decoder_activation, B, oh * ow, d.cout, groups(d.cout), GN_EPS, stats, st)) return 1;
-        if (d.has_attn && attention(d.attn, c2, B, oh * ow, st)) return 1;
+            if (d.has_attn && attention(d.attn, c2, B, oh * ow, st)) return 1;
+        }
         cur = c2; ch = oh; cw_ = ow;
     }
     {   // final block: no norms, no skip, no time, identity activation (score_unet.py:726-730, :757)
         const int ci = dec[3].cout;
-        float* up = wsalloc((size_t)B * H * W * ci);
-        if (!up) return 1;
         ConvParams p{};
         if (cfg.decoder_transpose) {
+            float* up = wsalloc((size_t)B * H * W * ci);
+            if (!up) return 1;
             float* a = wsalloc((size_t)B * H * W * ci);
             if (!a) return 1;
             p.x = cur; p.wp = fin_up.w->dev; p.out = up; p.bias = fin_up.b->dev; p.B = B; p.H = ch; p.W = cw_; p.Cs = ci; p.Cout = 4 * ci;
@@ -706,8 +754,7 @@ int sbgm_model::forward(const float* x, const float* t, const int64_t* y, const 
             if (sbgm_launch_depth_space2(up, a, B, ch, cw_, ci, 1, st)) return 1;
             return sbgm_launch_conv3x3_cout1(a, fin_conv.w->dev, fin_conv.b->dev, t, cfg.sigma, out, B, H, W, ci, st);
         }
-        if (sbgm_launch_upsample2x(cur, up, B, ch, cw_, ci, st)) return 1;
-        p.x = up; p.wp = fin_up.w->dev; p.wp_wino = fin_up.w->dev_wino; p.bias = fin_up.b->dev; p.B = B; p.H = H; p.W = W; p.Cs = ci; p.Cout = ci;
+        if (conv_up(fin_up, cur, ci, H, W, p, nullptr)) return 1;
         if (ci == 64) {
             // conv_up's 64-channel output feeds only the linear 3x3 Cout=1 conv: project onto its 9 taps in the epilogue
             // (9 floats per pixel instead of 64) and finish with a 9-point gather.
@@ -1021,7 +1068,7 @@ int sbgm_model_autotune(sbgm_model* m, int B, int H, int W, void* stream) {
 extern "C++" {
 static std::string conv_kernel_name(const sbgm_model::ConvRec& r) {
     char b[96];
-    if (r.t.lds) snprintf(b, sizeof b, "conv3x3_lds_kernel<%d; %d; %s; %s>", r.t.fco, r.t.fpx, r.t.wino ? "true" : "false", r.t.lds == 2 ? "true" : "false");
+    if (r.t.lds) snprintf(b, sizeof b, "conv3x3_lds_kernel<%d; %d; %s; %s; %d>", r.t.fco, r.t.fpx, r.t.wino ? "true" : "false", r.t.lds == 2 ? "true" : "false", r.in_mode);
     else if (r.t.wino) snprintf(b, sizeof b, "conv3x3_wino_kernel<%d; %d; %d>", r.t.fco, r.t.fpx, r.t.ws);
     else snprintf(b, sizeof b, "conv_igemm_kernel<%d; %d; %d; %d; %d; %d; %d; %d>", r.g.kh, r.g.kw, r.g.stride, r.g.pad, r.t.fco,
                   r.t.fpx, r.c_real == 2 ? 2 : (r.Cs >= 16 ? 0 : r.Cs), r.t.ws);
@@ -1029,17 +1076,17 @@ static std::string conv_kernel_name(const sbgm_model::ConvRec& r) {
 }
 }  // extern "C++"
 
-// Tile table <-> text file: one line per tuned convolution, "kh kw stride pad B H W Cin_pad Cout proj | fco fpx splits ws wino lds".
+// Tile table <-> text file: one line per tuned convolution, "kh kw stride pad B H W Cin_pad Cout proj in_mode | fco fpx splits ws wino lds".
 int sbgm_model_tune_save(sbgm_model* m, const char* path) {
     SBGM_CHECK(path, "tune_save: null path");
     FILE* f = fopen(path, "w");
     SBGM_CHECK(f, "tune_save: cannot open %s", path);
-    fprintf(f, "# sbgm conv tile table v1\n");
+    fprintf(f, "# sbgm conv tile table v2\n");
     for (auto& kv : m->tuned) {
         const ConvOpKey& k = kv.first;
         const ConvTile& t = kv.second;
-        fprintf(f, "%d %d %d %d %d %d %d %d %d %d | %d %d %d %d %d %d\n", k.kh, k.kw, k.s, k.p, k.B, k.H, k.W, k.Cs, k.Cout, k.proj,
-                t.fco, t.fpx, t.splits, t.ws, t.wino, t.lds);
+        fprintf(f, "%d %d %d %d %d %d %d %d %d %d %d | %d %d %d %d %d %d\n", k.kh, k.kw, k.s, k.p, k.B, k.H, k.W, k.Cs, k.Cout, k.proj,
+                k.in_mode, t.fco, t.fpx, t.splits, t.ws, t.wino, t.lds);
     }
     fclose(f);
     return 0;
@@ -1057,10 +1104,10 @@ int sbgm_model_tune_load(sbgm_model* m, const char* path) {
         if (line[0] == '#' || line[0] == '\n') continue;
         ConvOpKey k{};
         int t[6];
-        const int n = sscanf(line, "%d %d %d %d %d %d %d %d %d %d | %d %d %d %d %d %d", &k.kh, &k.kw, &k.s, &k.p, &k.B, &k.H, &k.W,
-                             &k.Cs, &k.Cout, &k.proj, &t[0], &t[1], &t[2], &t[3], &t[4], &t[5]);
+        const int n = sscanf(line, "%d %d %d %d %d %d %d %d %d %d %d | %d %d %d %d %d %d", &k.kh, &k.kw, &k.s, &k.p, &k.B, &k.H, &k.W,
+                             &k.Cs, &k.Cout, &k.proj, &k.in_mode, &t[0], &t[1], &t[2], &t[3], &t[4], &t[5]);
         // the launchers reject tiles they do not instantiate; here only the ranges that index memory are checked
-        const bool ok = n == 16 && (t[0] == 1 || t[0] == 2 || t[0] == 4) && (t[1] == 1 || t[1] == 2 || t[1] == 4) && t[2] >= 1 &&
+        const bool ok = n == 17 && k.in_mode >= 0 && k.in_mode <= 2 && (t[0] == 1 || t[0] == 2 || t[0] == 4) && (t[1] == 1 || t[1] == 2 || t[1] == 4) && t[2] >= 1 &&
                         t[2] <= 64 && (t[3] == 1 || t[3] == 2 || t[3] == 4 || t[3] == 8) && (t[4] | 1) == 1 && t[5] >= 0 && t[5] <= 2 &&
                         k.Cout % (16 * t[0]) == 0;
         if (!ok) {

@@ -224,6 +224,37 @@ __global__ __launch_bounds__(256) void groupnorm_apply_kernel(const float* __res
     }
 }
 
+// GroupNorm statistics -> per-(sample, channel) affine for the consumer convolution's load path (conv_lds.hip, input modes):
+// out[b][c/4][0][c%4] = rstd*gamma, out[b][c/4][1][c%4] = beta - mean*rstd*gamma (+ tbias[b][c]).  Same statistics expressions as
+// groupnorm_apply_kernel; one block per sample.
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restrict__ stats, int chunks, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const float* __restrict__ tbias,
+                                                          float* __restrict__ out, int HW, int C, int G, float eps) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* mr = reinterpret_cast<float*>(smem_raw);        // [G][2] mean, rstd
+    const int b = blockIdx.x, cpg = C / G;
+    for (int g = threadIdx.x; g < G; g += blockDim.x) {
+        double a = 0.0, a2 = 0.0;
+        const double* sp = stats + ((size_t)b * chunks * G + g) * 2;
+        for (int c = 0; c < chunks; ++c) { a += sp[(size_t)c * G * 2]; a2 += sp[(size_t)c * G * 2 + 1]; }
+        const double inv_n = 1.0 / ((double)HW * cpg);
+        const double mean = a * inv_n;
+        const double var = fmax(a2 * inv_n - mean * mean, 0.0);
+        mr[2 * g] = (float)mean;
+        mr[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        const int g = c / cpg;
+        const float a = gamma ? mr[2 * g + 1] * gamma[c] : mr[2 * g + 1];
+        float sh = (gamma ? beta[c] : 0.f) - mr[2 * g] * a;
+        if (tbias) sh += tbias[(size_t)b * C + c];
+        float* o = out + (((size_t)b * (C >> 2) + (c >> 2)) * 2) * 4 + (c & 3);
+        o[0] = a;
+        o[4] = sh;
+    }
+}
+
 // ---- K13: LayerNorm over C, one wave per token, two-pass in registers (wavefront shuffle reductions) ----------
 // reference score_unet.py:128-129, :141, :145 (eps 1e-5, affine)
 template <int VPL>   // float4 vectors per lane: C = 256 * VPL  (VPL = 0 -> generic strided path)
@@ -325,13 +356,9 @@ int sbgm_launch_groupnorm_apply(const float* x, float* y, const float* gamma, co
     return 0;
 }
 
-int sbgm_launch_groupnorm(const float* x, float* y, const float* gamma, const float* beta, const float* skip,
-                          const float* tbias, int act, int B, int HW, int C, int G, float eps, double* stats_ws,
-                          hipStream_t st, float* mr_out) {
+int sbgm_launch_gn_partial(const float* x, double* stats_ws, int B, int HW, int C, int G, int* chunks_out, hipStream_t st) {
     SBGM_CHECK(C % 4 == 0 && C <= 1024 && C % G == 0, "groupnorm: C=%d G=%d unsupported", C, G);
-    SBGM_CHECK((gamma == nullptr) == (beta == nullptr), "groupnorm: gamma and beta must both be set or both null");
-    // pass 1: per-(sample, pixel-chunk, group) partial sums, plain stores (no zeroing, no atomics, deterministic);
-    // pass 2: every apply block re-reduces its sample's <= GN_MAX_CHUNKS partials into LDS, then streams.
+    // per-(sample, pixel-chunk, group) partial sums, plain stores (no zeroing, no atomics, deterministic)
     const int lanes_px = std::max(1, NORM_THREADS / (C / 4));
     int chunks = std::max(1, std::min(GN_MAX_CHUNKS, HW / (lanes_px * 16)));
     const int ppb = (HW + chunks - 1) / chunks;
@@ -339,12 +366,27 @@ int sbgm_launch_groupnorm(const float* x, float* y, const float* gamma, const fl
     hipLaunchKernelGGL(gn_partial_kernel, dim3(chunks, B), dim3(NORM_THREADS), 2 * C * sizeof(double) + 8192, st, x, stats_ws,
                        HW, C, G, ppb);
     SBGM_LAUNCH_CHECK();
-    const size_t per_sample = (size_t)HW * (C / 4);
-    const int bx = (int)std::max<size_t>(1, std::min<size_t>((per_sample + 255) / 256, GN_APPLY_BLOCKS / std::max(1, B) + 1));
-    hipLaunchKernelGGL(groupnorm_apply_kernel, dim3(bx, B), dim3(256), 2 * G * sizeof(float), st, x, y, gamma, beta, skip, tbias,
-                       act, HW, C, G, chunks, eps, stats_ws, mr_out);
+    *chunks_out = chunks;
+    return 0;
+}
+
+int sbgm_launch_gn_finalize(const double* stats, int chunks, const float* gamma, const float* beta, const float* tbias, float* out,
+                            int B, int HW, int C, int G, float eps, hipStream_t st) {
+    SBGM_CHECK(C % 4 == 0 && C <= 1024 && C % G == 0 && chunks >= 1 && chunks <= GN_MAX_CHUNKS, "gn_finalize: C=%d G=%d chunks=%d", C, G, chunks);
+    SBGM_CHECK((gamma == nullptr) == (beta == nullptr), "gn_finalize: gamma and beta must both be set or both null");
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(B), dim3(256), 2 * G * sizeof(float), st, stats, chunks, gamma, beta, tbias, out, HW, C, G, eps);
     SBGM_LAUNCH_CHECK();
     return 0;
+}
+
+int sbgm_launch_groupnorm(const float* x, float* y, const float* gamma, const float* beta, const float* skip,
+                          const float* tbias, int act, int B, int HW, int C, int G, float eps, double* stats_ws,
+                          hipStream_t st, float* mr_out) {
+    SBGM_CHECK((gamma == nullptr) == (beta == nullptr), "groupnorm: gamma and beta must both be set or both null");
+    // pass 1: chunk partials; pass 2: every apply block re-reduces its sample's <= GN_MAX_CHUNKS partials into LDS, then streams.
+    int chunks = 0;
+    if (sbgm_launch_gn_partial(x, stats_ws, B, HW, C, G, &chunks, st)) return 1;
+    return sbgm_launch_groupnorm_apply(x, y, gamma, beta, skip, tbias, act, B, HW, C, G, eps, stats_ws, chunks, st, mr_out);
 }
 
 int sbgm_launch_layernorm(const float* x, float* y, const float* gamma, const float* beta, int M, int C, float eps,

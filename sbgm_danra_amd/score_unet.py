@@ -426,9 +426,9 @@ _LOSS_RNG = {}       # device -> int64[2] (Philox seed, offset) used by captured
 
 def _loss_rng_state(dev):
     st = _LOSS_RNG.get(dev)
-    if st is None:
-        from .score_sampling import _fresh_seed
-        st = _LOSS_RNG[dev] = torch.tensor([_fresh_seed(), 0], dtype=torch.int64, device=dev)
+    if st is None:        # derived from torch's seed WITHOUT drawing from the generator (eager calls draw their own seed per call)
+        seed = (torch.initial_seed() * 0x9E3779B97F4A7C15 + 0x2545F4914F6CDD1D) & 0x7FFFFFFFFFFFFFFF
+        st = _LOSS_RNG[dev] = torch.tensor([seed, 0], dtype=torch.int64, device=dev)
     return st
 
 

@@ -23,6 +23,16 @@ def leaf(t):
 
 
 B, H, Cc = 2, 16, 64
+_T2 = None
+
+
+def _t2():
+    global _T2
+    if _T2 is None:
+        _T2 = torch.tensor([0.1, 0.7], device="cuda")      # created outside any capture (host -> device copy)
+    return _T2
+
+
 OPS = {
     "conv3x3+bias+res+tbias": lambda: ([leaf(rnd(B, H, H, Cc)), leaf(rnd(Cc, Cc, 3, 3, seed=1) * 0.05), leaf(rnd(Cc, seed=2)),
                                         leaf(rnd(B, H, H, Cc, seed=3)), leaf(rnd(B, Cc, seed=4))],
@@ -45,7 +55,7 @@ OPS = {
     "upsample": lambda: ([leaf(rnd(B, H, H, Cc))], lambda x: T.UpsampleFn.apply(x)),
     "gelu": lambda: ([leaf(rnd(512, 128))], lambda x: T.ActFn.apply(x, N.GELU)),
     "final conv": lambda: ([leaf(rnd(B, H, H, Cc)), leaf(rnd(1, Cc, 3, 3, seed=1) * 0.05), leaf(rnd(1, seed=2))],
-                           lambda a, w, b: T.Cout1Fn.apply(a, w, b, torch.tensor([0.1, 0.7], device="cuda"), 25.0)),
+                           lambda a, w, b: T.Cout1Fn.apply(a, w, b, _t2(), 25.0)),
 }
 
 
@@ -70,6 +80,7 @@ def _capture(step, leaves):
 def test_every_training_op_replays_identically(name):
     leaves, fn = OPS[name]()
     dev = leaves[0].device
+    _t2()
 
     def step(zero=True):
         if zero:
