@@ -181,6 +181,16 @@ typedef struct sbgm_conv_args {
     int out_h, out_w;        /* explicit output size (required with in_dil = 2), else 0 */
     float* ws;
     int64_t ws_floats;
+    /* LDS-staged kernel only (winograd bits 0+1): what happens to the input while the halo patch is staged, i.e. the
+     * normalisation / resampling passes between the convolutions of a DecoderBlock (score_unet.py:583-615) without a pass of
+     * their own.  0 = plain.  1 = affine on load: the convolution sees x*scale + shift per (sample, channel) (a GroupNorm of x,
+     * in_affine from sbgm_groupnorm_finalize), zero padding kept.  2 = nn.Upsample(x2, bilinear, align_corners=False) on load:
+     * x is the LOW-resolution map [B,H/2,W/2,c_pad] (H, W = the convolution's size), optionally act(x*scale + shift + in_skip)
+     * first. */
+    int in_mode;
+    const float* in_affine;  /* [B][c_pad/4][2][4] scale quad, shift quad; required for mode 1, optional for mode 2 */
+    const float* in_skip;    /* mode 2: [B,H/2,W/2,c_pad] or NULL */
+    int in_act;              /* mode 2: SBGM_NONE / RELU / SILU / GELU applied to the low-resolution value */
 } sbgm_conv_args;
 int sbgm_conv2d_fwd(const sbgm_conv_args* a, void* stream);
 /* Times the kernel / tile / split candidates for exactly this call (same operands; launches are idempotent; synchronises)
@@ -221,6 +231,13 @@ int sbgm_upsample2x_fwd(const float* x, float* y, int B, int H, int W, int C, vo
 int sbgm_groupnorm_fwd(const float* x, float* y, const float* gamma, const float* beta, const float* skip,
                        const float* tbias, int act, int B, int HW, int C, int G, float eps, void* stats_ws,
                        float* mean_rstd_out /* [B,G,2] or NULL */, void* stream);
+/* GroupNorm statistics only (the chunk partials sbgm_groupnorm_fwd computes first): stats_ws as above; *chunks receives the
+ * number of partials per (sample, group).  Then sbgm_groupnorm_finalize turns them into the per-(sample, channel) affine a
+ * consumer convolution applies on load (sbgm_conv_args.in_affine): out[b][c/4][0][c%4] = rstd*gamma,
+ * out[b][c/4][1][c%4] = beta - mean*rstd*gamma (+ tbias[b][c]).  gamma/beta NULL = no affine. */
+int sbgm_groupnorm_stats(const float* x, void* stats_ws, int B, int HW, int C, int G, int* chunks, void* stream);
+int sbgm_groupnorm_finalize(const void* stats_ws, int chunks, const float* gamma, const float* beta, const float* tbias,
+                            float* out /* [B][C][2] */, int B, int HW, int C, int G, float eps, void* stream);
 /* nn.LayerNorm(C).  score_unet.py:128-129 */
 int sbgm_layernorm_fwd(const float* x, float* y, const float* gamma, const float* beta, int M, int C, float eps, void* stream);
 /* nn.BatchNorm2d in training mode (+ residual, ReLU, time bias).  stats_ws: >= 24*C bytes; its first 16*C bytes are the

@@ -59,7 +59,7 @@ class ConvArgs(C.Structure):
                 ("residual", _vp), ("B", _i), ("H", _i), ("W", _i), ("c_pad", _i), ("Cout", _i), ("KH", _i), ("KW", _i),
                 ("stride", _i), ("pad", _i), ("act", _i), ("tbias_after_act", _i), ("tile_co", _i), ("tile_px", _i),
                 ("splits", _i), ("waves_per_tile", _i), ("winograd", _i), ("in_dil", _i), ("out_h", _i), ("out_w", _i), ("ws", _vp),
-                ("ws_floats", _i64)]
+                ("ws_floats", _i64), ("in_mode", _i), ("in_affine", _vp), ("in_skip", _vp), ("in_act", _i)]
 
 
 # name -> (restype, argtypes); every symbol include/sbgm_hip.h declares
@@ -109,6 +109,8 @@ SIGNATURES = {
     "sbgm_conv_wino_pack_weight": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "sbgm_upsample2x_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "sbgm_groupnorm_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
+    "sbgm_groupnorm_stats": (_i, [_vp, _vp, _i, _i, _i, _i, C.POINTER(_i), _vp]),
+    "sbgm_groupnorm_finalize": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     "sbgm_layernorm_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _f, _vp]),
     "sbgm_batchnorm_train_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
     "sbgm_batchnorm_train_stats": (_i, [_vp, _i, _i, _i, _vp, _vp]),

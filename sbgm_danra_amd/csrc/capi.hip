@@ -42,6 +42,8 @@ int sbgm_conv2d_fwd(const sbgm_conv_args* a, void* stream) {
     SBGM_CHECK(a->act == SBGM_NONE || a->act == SBGM_RELU || a->act == SBGM_GELU, "conv2d: act must be none, relu or gelu");
     p.tbias_after_act = a->tbias_after_act;
     p.in_dil = a->in_dil; p.out_h = a->out_h; p.out_w = a->out_w;
+    p.in_mode = a->in_mode; p.in_affine = a->in_affine; p.in_skip = a->in_skip; p.in_act = a->in_act;
+    SBGM_CHECK(a->in_mode == 0 || (a->winograd & 3) == 3, "conv2d: in_mode %d needs the LDS-staged Winograd kernel (winograd bits 0 and 1)", a->in_mode);
     ConvTile t{a->tile_co ? a->tile_co : (a->Cout % 64 == 0 ? 4 : 2), a->tile_px ? a->tile_px : 2, a->splits ? a->splits : 1,
                a->waves_per_tile ? a->waves_per_tile : 1, a->winograd & 1, (a->winograd & 2) ? ((a->winograd & 4) ? 2 : 1) : 0};
     if (a->winograd & 2) {
@@ -90,6 +92,14 @@ int sbgm_batchnorm_bwd_apply(const float* x, const float* dy, const float* y, co
                              const float* sync_sums, double n_total, int B, int HW, int C, void* stream) {
     return sbgm_launch_batchnorm_bwd_apply(x, dy, y, gamma, tbias_after, mean_rstd, relu, dx, dres, dgamma, dbeta, ws, sync_sums, n_total,
                                            B, HW, C, ST);
+}
+int sbgm_groupnorm_stats(const float* x, void* stats_ws, int B, int HW, int C, int G, int* chunks, void* stream) {
+    SBGM_CHECK(chunks != nullptr, "groupnorm_stats: chunks is required");
+    return sbgm_launch_gn_partial(x, static_cast<double*>(stats_ws), B, HW, C, G, chunks, ST);
+}
+int sbgm_groupnorm_finalize(const void* stats_ws, int chunks, const float* gamma, const float* beta, const float* tbias, float* out, int B,
+                            int HW, int C, int G, float eps, void* stream) {
+    return sbgm_launch_gn_finalize(static_cast<const double*>(stats_ws), chunks, gamma, beta, tbias, out, B, HW, C, G, eps, ST);
 }
 int sbgm_dsm_loss_blocks(int64_t per_sample) { return sbgm_dsm_nblk(per_sample); }
 int sbgm_dsm_perturb(const float* x, const float* z, const float* t, const uint64_t* rng_state, uint64_t seed, float t_eps, float sigma,

@@ -18,9 +18,13 @@
 //           finalised into `in_affine` by gn_finalize_kernel); out-of-image pixels stay 0 (zero padding of the NORMALISED map)
 //   IN = 2  bilinear x2 on load (nn.Upsample, align_corners=False): x is the LOW-resolution map [B][H/2][W/2][Cs].  Per stage
 //           the (TH/2+2) x 10 low-res pixels under the patch are loaded (edge-clamped), optionally transformed
-//           act(x*scale + shift + skip) (the pending GroupNorm + skip + time bias + activation of the previous block), parked
-//           in a small LDS region and expanded into the 18-wide patch with PyTorch's 0.25 / 0.75 taps.  The upsampled tensor
-//           (134 MB at the final block of a B=32, 128x128 evaluation) is never written or re-read.
+//           act(x*scale + shift + skip) (the pending GroupNorm + skip + time bias + activation of the previous block) and parked
+//           in a small LDS region.  The interpolation is separable: the staging step blends ROWS only (0.25 / 0.75 taps) into a
+//           patch of (TH+2) high-res rows x 10 LOW-res columns, and the column taps are folded into the Winograd input transform
+//           of the sweep: the 4 columns d0..d3 a pair needs are combinations of just 3 low-res neighbours,
+//             d0 = .75 a + .25 b   d1 = .25 a + .75 b   d2 = .75 b + .25 c   d3 = .25 b + .75 c     (a, b, c = x[m-1], x[m], x[m+1])
+//           so a B fragment costs 3 LDS reads instead of 4 and the 18-wide patch is never built.  The upsampled tensor (134 MB
+//           at the final block of a B=32, 128x128 evaluation) is never written or re-read.
 #include "common.h"
 #include "kernels.h"
 #include "conv_common.h"
@@ -161,36 +165,43 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(const ConvParams p) {
             f32x4 v = rp[u];
             if (p.in_affine != nullptr) v = v * sc + sh;
             if (p.in_skip != nullptr) v += rs[u];
-            if (p.in_act != SBGM_ACT_NONE) {
+            if (p.in_act == SBGM_ACT_SILU) {                 // hardware exp2 / rcp (1 ulp each): the exact expf + division cost 7 % of the
+#pragma unroll                                               // launch, recomputed for every halo; the budget is 1e-4
+                for (int e = 0; e < 4; ++e) v[e] = v[e] * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v[e]));
+            } else if (p.in_act != SBGM_ACT_NONE) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = sbgm_act(v[e], p.in_act);
             }
             if (q < LQ) ld[q] = v;
         }
     };
-    auto expand = [&](int lbuf, int buf) {                     // IN == 2: L region -> 18-wide patch, bilinear x2 (align_corners=False)
+    constexpr int PQ2 = PH * LW * 4;                           // IN == 2: patch quads = high-res rows x low-res columns
+    constexpr int PPT2 = (PQ2 + 255) / 256;
+    auto expand = [&](int lbuf, int buf) {                     // IN == 2: L region -> row-interpolated patch [PH][LW]
+        static_assert(IN != 2 || WINO, "upsample-on-load is built on the Winograd sweep");
         const f32x4* ls = lr0 + lbuf * LQ;
         f32x4* pd = pt0 + buf * STAGE_QUADS;
-#pragma unroll 1                                             // one quad at a time: 4 reads + blend stay out of the accumulators' way
-        for (int u = 0; u < PPT; ++u) {
+#pragma unroll
+        for (int u = 0; u < PPT2; ++u) {
             const int q = tid + 256 * u;
             const int quad = q & 3, pix = q >> 2;
-            const int py = pix / PWID, px = pix - py * PWID;
-            const int iy = y0 - 1 + py, ix = x0 - 1 + px;
-            const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
-            // rows a = py >> 1, b = a + 1 of the L region (y0, x0 are even); weights as PyTorch: even output row 0.25 / 0.75
-            // (row 0: 0 / 1), odd output row 0.75 / 0.25
-            const int ra = py >> 1, ca = px >> 1;
+            const int py = pix / LW, c = pix - py * LW;
+            const int iy = y0 - 1 + py;
+            // output row iy blends L rows a = py >> 1 and a + 1 (y0 is even); weights as PyTorch: even row 0.25 / 0.75 (row 0: 0 / 1),
+            // odd row 0.75 / 0.25; rows outside the image are the convolution's zero padding
+            const int ra = py >> 1;
             const float wya = (py & 1) ? (iy == 0 ? 0.f : 0.25f) : 0.75f, wyb = 1.f - wya;
-            const float wxa = (px & 1) ? (ix == 0 ? 0.f : 0.25f) : 0.75f, wxb = 1.f - wxa;
-            if (q < PQ) {
-                const f32x4 v00 = ls[(ra * LW + ca) * 4 + quad], v01 = ls[(ra * LW + ca + 1) * 4 + quad];
-                const f32x4 v10 = ls[((ra + 1) * LW + ca) * 4 + quad], v11 = ls[((ra + 1) * LW + ca + 1) * 4 + quad];
-                const f32x4 o = wya * (wxa * v00 + wxb * v01) + wyb * (wxa * v10 + wxb * v11);
-                pd[py * PWS * 4 + swz(px, quad)] = ok ? o : f32x4{0.f, 0.f, 0.f, 0.f};
+            if (q < PQ2) {
+                const f32x4 va = ls[(ra * LW + c) * 4 + quad], vb = ls[((ra + 1) * LW + c) * 4 + quad];
+                const f32x4 o = wya * va + wyb * vb;
+                pd[(py * LW + c) * 4 + ((quad + 2 * (py & 1)) & 3)] = (unsigned)iy < (unsigned)p.H ? o : f32x4{0.f, 0.f, 0.f, 0.f};
             }
         }
     };
+    const bool up_zero_left = IN == 2 && x0 == 0 && (r16 & 7) == 0;
+    const bool up_zero_right = IN == 2 && x0 + TW == p.W && (r16 & 7) == 7;
+    const float up_a0 = up_zero_left ? 0.f : 0.75f, up_b0 = up_zero_left ? -0.75f : -0.5f;      // v0 = d0 - d2
+    const float up_b3 = up_zero_right ? 0.75f : 0.5f, up_c3 = up_zero_right ? 0.f : -0.75f;     // v3 = d1 - d3
     stage_load(0);
     stage_store_w(0);
     if (IN != 2) {
@@ -245,11 +256,25 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(const ConvParams p) {
 #pragma unroll
                 for (int j = 0; j < FPX; ++j) {
                     const int prow = wave * FPX * 2 + 2 * j + (r16 >> 3) + kh;     // patch row
-                    const int pcol = 2 * (r16 & 7);                                   // patch col of d0 (= ox0 - 1 - (x0 - 1))
-                    const f32x4* src = pt + prow * PWS * 4;
-                    const f32x4 d0 = src[swz(pcol, kq)], d1 = src[swz(pcol + 1, kq)], d2 = src[swz(pcol + 2, kq)],
-                                d3 = src[swz(pcol + 3, kq)];
-                    v[0][j] = d0 - d2; v[1][j] = d1 + d2; v[2][j] = d2 - d1; v[3][j] = d1 - d3;
+                    if (IN != 2) {
+                        const int pcol = 2 * (r16 & 7);                               // patch col of d0 (= ox0 - 1 - (x0 - 1))
+                        const f32x4* src = pt + prow * PWS * 4;
+                        const f32x4 d0 = src[swz(pcol, kq)], d1 = src[swz(pcol + 1, kq)], d2 = src[swz(pcol + 2, kq)],
+                                    d3 = src[swz(pcol + 3, kq)];
+                        v[0][j] = d0 - d2; v[1][j] = d1 + d2; v[2][j] = d2 - d1; v[3][j] = d1 - d3;
+                    } else {
+                        // low-res neighbours a, b, c of output pair (r16 & 7); quad rotation (kq + 2*(row & 1)) & 3: the 16 lanes of a
+                        // ds_read_b128 group hit 16 distinct slots (4 consecutive columns x {2 quads} x {2 row parities}).
+                        // d0..d3 (header comment) substituted into V = B^T d; at the image's left / right edge d0 / d3 is the
+                        // convolution's zero padding, which only changes the coefficients of v0 / v3
+                        const f32x4* src = pt + (prow * LW + (r16 & 7)) * 4;
+                        const int rot = (kq + 2 * (prow & 1)) & 3;
+                        const f32x4 xa = src[rot], xb = src[4 + rot], xc = src[8 + rot];
+                        v[0][j] = up_a0 * xa + up_b0 * xb - 0.25f * xc;
+                        v[1][j] = 0.25f * (xa + xc) + 1.5f * xb;
+                        v[2][j] = 0.25f * (xc - xa);
+                        v[3][j] = 0.25f * xa + up_b3 * xb + up_c3 * xc;
+                    }
                 }
 #pragma unroll
                 for (int xi = 0; xi < 4; ++xi) {

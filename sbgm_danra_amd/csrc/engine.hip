@@ -655,13 +655,16 @@ int sbgm_model::forward(const float* x, const float* t, const int64_t* y, const 
     // low-resolution map and interpolates while staging (in_mode 2, with the PREVIOUS block's pending GroupNorm + skip + time
     // bias + activation applied to the low-res pixels), `conv` reads conv_up's raw output through norm1's affine (in_mode 1);
     // the statistics come out of the producing convolution's epilogue and one tiny finalize launch turns them into the
-    // per-(sample, channel) scale / shift.  A block whose output feeds attention, and maps narrower than 16 pixels (wave-level
-    // kernels), keep the separate passes.  SBGM_NO_FUSED_DECODER=1 forces the separate passes everywhere.
+    // per-(sample, channel) scale / shift.  A block whose output feeds attention keeps the separate apply pass, and so do maps
+    // narrower than 32 pixels: the fused staging costs the (compute-bound) convolution 2-4 us more than the plain one (measured,
+    // tools/bench_fused_conv.py), which only pays where the pass it replaces streams more than ~8 MB (64 / 128 channels at
+    // 32x32 and up; at 16x16 x 256 channels the separate 4 us pass is cheaper).  SBGM_NO_FUSED_DECODER=1 forces the separate
+    // passes everywhere.
     const int G_of = cfg.gn_groups;
     auto groups = [&](int c) { return cfg.decoder_norm == SBGM_NORM_GROUP ? std::max(1, std::min(G_of, c)) : c; };
     static const bool fused_ok = getenv("SBGM_NO_FUSED_DECODER") == nullptr && getenv("SBGM_NO_LDS_CONV") == nullptr && getenv("SBGM_NO_WINOGRAD") == nullptr;
     auto can_fuse = [&](const ConvW& cw, int c_in, int w_out) {
-        return fused_ok && !cfg.decoder_transpose && w_out % 16 == 0 && c_in % 16 == 0 && cw.w->dev_wino != nullptr;
+        return fused_ok && !cfg.decoder_transpose && w_out >= 32 && w_out % 16 == 0 && c_in % 16 == 0 && cw.w->dev_wino != nullptr;
     };
     struct Pending { const float* raw; const float* affine; const float* skip; int act; bool live; } pend{nullptr, nullptr, nullptr, SBGM_ACT_NONE, false};
     // statistics of `t` [B][hw][c] for its GroupNorm: from the convolution epilogue (chunks > 0) or a separate partial pass

@@ -233,15 +233,21 @@ __global__ __launch_bounds__(256) void gn_finalize_kernel(const double* __restri
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* mr = reinterpret_cast<float*>(smem_raw);        // [G][2] mean, rstd
     const int b = blockIdx.x, cpg = C / G;
-    for (int g = threadIdx.x; g < G; g += blockDim.x) {
-        double a = 0.0, a2 = 0.0;
+    // one wavefront-sized team per group sums the <= 64 chunk partials with shuffles (fixed order: deterministic); a serial loop
+    // per group made this launch 7 us of pure latency
+    const int lane = threadIdx.x & 63, team = threadIdx.x >> 6;
+    for (int g = team; g < G; g += 4) {
         const double* sp = stats + ((size_t)b * chunks * G + g) * 2;
-        for (int c = 0; c < chunks; ++c) { a += sp[(size_t)c * G * 2]; a2 += sp[(size_t)c * G * 2 + 1]; }
-        const double inv_n = 1.0 / ((double)HW * cpg);
-        const double mean = a * inv_n;
-        const double var = fmax(a2 * inv_n - mean * mean, 0.0);
-        mr[2 * g] = (float)mean;
-        mr[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+        double a = lane < chunks ? sp[(size_t)lane * G * 2] : 0.0, a2 = lane < chunks ? sp[(size_t)lane * G * 2 + 1] : 0.0;
+        a = wave_sum_d(a);
+        a2 = wave_sum_d(a2);
+        if (lane == 0) {
+            const double inv_n = 1.0 / ((double)HW * cpg);
+            const double mean = a * inv_n;
+            const double var = fmax(a2 * inv_n - mean * mean, 0.0);
+            mr[2 * g] = (float)mean;
+            mr[2 * g + 1] = (float)(1.0 / sqrt(var + (double)eps));
+        }
     }
     __syncthreads();
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
