@@ -256,12 +256,6 @@ int sbgm_batchnorm_train_apply(const float* x, float* y, const float* gamma, con
                                float eps, float momentum, void* stats_ws, double n_total, float* mean_rstd_out, void* stream);
 /* Core of nn.MultiheadAttention between in_proj and out_proj: qkv [B,S,3C] -> [B,S,C].  score_unet.py:142 */
 int sbgm_mha_core_fwd(const float* qkv, float* out, int B, int S, int C, int heads, void* stream);
-/* nn.Linear over tokens with its element-wise neighbours in ImageSelfAttention fused (score_unet.py:127-134, :141-145):
- *   out[M,N] = act( LayerNorm?(x[M,K]) @ W^T + bias ) [+ res]
- * w_packed: the [N,K] weight packed by sbgm_conv_pack_weight as a 1x1 kernel (c_pad = K).  ln_gamma/ln_beta NULL = no
- * LayerNorm; act SBGM_NONE or SBGM_GELU (exact erf); res NULL = none.  K %% 32 == 0, N %% 64 == 0. */
-int sbgm_token_linear_fwd(const float* x, const float* w_packed, const float* bias, const float* res, const float* ln_gamma,
-                          const float* ln_beta, float* out, int M, int K, int N, int act, float ln_eps, void* stream);
 /* SinusoidalEmbedding (+ label embedding) -> SiLU -> Linear, for one projection.  score_unet.py:41-45, :377-381 */
 int sbgm_time_proj_fwd(const float* t, const int64_t* y, const float* label_emb, const float* freqs, const float* weight,
                        const float* bias, float* out, float* emb_ws /* [B,D] silu(emb) */, float* emb_raw /* [B,D] or NULL */,

@@ -93,13 +93,6 @@ int sbgm_batchnorm_bwd_apply(const float* x, const float* dy, const float* y, co
     return sbgm_launch_batchnorm_bwd_apply(x, dy, y, gamma, tbias_after, mean_rstd, relu, dx, dres, dgamma, dbeta, ws, sync_sums, n_total,
                                            B, HW, C, ST);
 }
-int sbgm_token_linear_fwd(const float* x, const float* w_packed, const float* bias, const float* res, const float* ln_gamma,
-                          const float* ln_beta, float* out, int M, int K, int N, int act, float ln_eps, void* stream) {
-    TokenGemmParams p{};
-    p.x = x; p.wp = w_packed; p.bias = bias; p.res = res; p.ln_g = ln_gamma; p.ln_b = ln_beta; p.out = out;
-    p.M = M; p.K = K; p.N = N; p.act = act; p.ln_eps = ln_eps;
-    return sbgm_launch_token_gemm(p, ST);
-}
 int sbgm_groupnorm_stats(const float* x, void* stats_ws, int B, int HW, int C, int G, int* chunks, void* stream) {
     SBGM_CHECK(chunks != nullptr, "groupnorm_stats: chunks is required");
     return sbgm_launch_gn_partial(x, static_cast<double*>(stats_ws), B, HW, C, G, chunks, ST);

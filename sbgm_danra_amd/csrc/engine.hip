@@ -501,11 +501,11 @@ int sbgm_model::conv(const ConvGeom& g, ConvParams p, hipStream_t st) {
     return rc;
 }
 
-// y = h + FF(LN2(h)),  h = x + MHA(LN1(x))   over tokens [B*S, C]  (score_unet.py:136-148); in place on x.
-// 5 launches: LN1+in_proj | attention core | out_proj+residual | LN2+FF1+GELU | FF2+residual  (token_gemm.hip); shapes outside
-// that kernel's domain (C not a multiple of 32/64) take the general path: LayerNorm launches + 1x1 implicit GEMMs.
+// y = h + FF(LN2(h)),  h = x + MHA(LN1(x))   over tokens [B*S, C]  (score_unet.py:136-148); in place on x
 int sbgm_model::attention(const AttnW& a, float* x, int B, int S, hipStream_t st) {
     const int C = a.C, M = B * S;
+    float* n1 = wsalloc((size_t)M * C);
+    if (!n1) return 1;
     float* qkv = wsalloc((size_t)M * 3 * C);
     if (!qkv) return 1;
     float* att = wsalloc((size_t)M * C);
@@ -514,22 +514,6 @@ int sbgm_model::attention(const AttnW& a, float* x, int B, int S, hipStream_t st
     if (!h) return 1;
     float* f1 = wsalloc((size_t)M * C);
     if (!f1) return 1;
-    static const bool fused = getenv("SBGM_NO_TOKEN_GEMM") == nullptr;
-    if (fused && !prof && sbgm_token_gemm_supported(M, C, C) && sbgm_token_gemm_supported(M, C, 3 * C)) {
-        TokenGemmParams p{};
-        p.M = M; p.K = C; p.ln_eps = LN_EPS;
-        p.x = x; p.wp = a.inw->dev; p.bias = a.inb->dev; p.ln_g = a.ln1g->dev; p.ln_b = a.ln1b->dev; p.out = qkv; p.N = 3 * C;
-        if (sbgm_launch_token_gemm(p, st)) return 1;
-        if (sbgm_launch_mha_core(qkv, att, B, S, C, cfg.n_heads, st)) return 1;
-        p.x = att; p.wp = a.outw->dev; p.bias = a.outb->dev; p.ln_g = p.ln_b = nullptr; p.res = x; p.out = h; p.N = C;
-        if (sbgm_launch_token_gemm(p, st)) return 1;
-        p.x = h; p.wp = a.f1w->dev; p.bias = a.f1b->dev; p.ln_g = a.ln2g->dev; p.ln_b = a.ln2b->dev; p.res = nullptr; p.act = SBGM_ACT_GELU; p.out = f1;   // :131-132
-        if (sbgm_launch_token_gemm(p, st)) return 1;
-        p.x = f1; p.wp = a.f2w->dev; p.bias = a.f2b->dev; p.ln_g = p.ln_b = nullptr; p.res = h; p.act = SBGM_ACT_NONE; p.out = x;
-        return sbgm_launch_token_gemm(p, st);
-    }
-    float* n1 = wsalloc((size_t)M * C);
-    if (!n1) return 1;
     const ConvGeom lin{1, 1, 1, 0};
     if (sbgm_launch_layernorm(x, n1, a.ln1g->dev, a.ln1b->dev, M, C, LN_EPS, st)) return 1;
     ConvParams p{};

@@ -155,23 +155,6 @@ int sbgm_launch_batchnorm_bwd_apply(const float* x, const float* dy, const float
                                     const float* mr, int relu, float* dx, float* dres, float* dgamma, float* dbeta, const float* s12_ws,
                                     const float* sync_sums, double n_total, int B, int HW, int C, hipStream_t st);
 
-// ---- token_gemm.hip: out = act(LayerNorm?(x) @ W^T + bias) [+ res] over tokens (the attention blocks' nn.Linear layers) --------
-struct TokenGemmParams {
-    const float* x;        // [M][K] tokens
-    const float* wp;       // weights packed by sbgm_launch_pack_conv_weight as a 1x1 kernel: [K/16][N][16]
-    const float* bias;     // [N] or null
-    const float* res;      // [M][N] or null, added after the activation
-    const float* ln_g;     // [K] or null: LayerNorm over K before the product ...
-    const float* ln_b;     // ... with this affine
-    float* out;            // [M][N]
-    int M, K, N;
-    int act;               // SBGM_ACT_NONE or SBGM_ACT_GELU (exact erf)
-    float ln_eps;
-    uint32_t w_bytes;      // filled by the launcher
-};
-int sbgm_token_gemm_supported(int M, int K, int N);
-int sbgm_launch_token_gemm(TokenGemmParams p, hipStream_t st);
-
 // ---- attention.hip -------------------------------------------------------------------------------------
 int sbgm_launch_mha_core(const float* qkv, float* out, int B, int S, int C, int heads, hipStream_t st);
 

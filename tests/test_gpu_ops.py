@@ -416,39 +416,3 @@ def test_batched_weight_pack_equals_single_packs(transposed):
     assert len(outs) >= 4
     for single, batched in outs:
         assert torch.equal(single, batched)
-
-
-# ---- token_gemm.hip: nn.Linear over tokens with LayerNorm / GELU / residual fused (the attention blocks' 4 linears) ----------
-@pytest.mark.parametrize("M,K,Nn", [(2048, 256, 768), (2048, 256, 256), (512, 512, 1536), (512, 512, 512), (8192, 128, 384), (8192, 128, 128),
-                                    (37, 128, 64), (16, 64, 128), (1, 32, 64), (100, 96, 192), (4, 1024, 64)])
-@pytest.mark.parametrize("variant", ["plain", "ln", "ln+gelu", "res", "gelu+res"])
-def test_token_linear(M, K, Nn, variant):
-    g = torch.Generator().manual_seed(M + K + Nn)
-    x = torch.randn(M, K, generator=g) * 1.5 + 0.3
-    w, b = torch.randn(Nn, K, generator=g) / math.sqrt(K), torch.randn(Nn, generator=g) * 0.1
-    gam, bet = torch.randn(K, generator=g) * 0.2 + 1.0, torch.randn(K, generator=g) * 0.1
-    res = torch.randn(M, Nn, generator=g)
-    ln, gelu, with_res = "ln" in variant, "gelu" in variant, "res" in variant
-    want = F.linear(F.layer_norm(x, (K,), gam, bet, 1e-5) if ln else x, w, b)
-    if gelu:
-        want = F.gelu(want)
-    if with_res:
-        want = want + res
-    wd = w.view(Nn, K, 1, 1).contiguous().to(DEV)
-    packed = torch.empty(lib().sbgm_conv_packed_numel(Nn, 1, 1, K), device=DEV)
-    N.check(lib().sbgm_conv_pack_weight(wd.data_ptr(), packed.data_ptr(), Nn, K, 1, 1, K, N.stream()))
-    xd, bd, out = x.to(DEV), b.to(DEV), torch.empty(M, Nn, device=DEV)
-    gd, btd = (gam.to(DEV), bet.to(DEV)) if ln else (None, None)
-    rd = res.to(DEV) if with_res else None
-    N.check(lib().sbgm_token_linear_fwd(xd.data_ptr(), packed.data_ptr(), bd.data_ptr(), N.ptr(rd), N.ptr(gd), N.ptr(btd), out.data_ptr(), M, K, Nn,
-                                        N.GELU if gelu else N.NONE, 1e-5, N.stream()))
-    torch.cuda.synchronize()
-    assert relerr(out.cpu(), want) < 1e-5
-
-
-def test_token_linear_rejects_unsupported_shapes():
-    x = torch.zeros(4, 48, device=DEV)
-    with pytest.raises(N.NativeError):
-        N.check(lib().sbgm_token_linear_fwd(x.data_ptr(), x.data_ptr(), None, None, None, None, x.data_ptr(), 4, 48, 64, 0, 1e-5, N.stream()))
-    with pytest.raises(N.NativeError):
-        N.check(lib().sbgm_token_linear_fwd(x.data_ptr(), x.data_ptr(), None, None, None, None, x.data_ptr(), 4, 64, 48, 0, 1e-5, N.stream()))
