@@ -10,7 +10,8 @@
 //                                       k = 4*(lane>>4)+reg, so P never leaves registers and V is indexed to match.
 // Queries sit on lane&15 in both products, so the running max / sum / rescale are lane-local, and the softmax
 // reductions over keys are 3 in-register ops + 2 wavefront shuffles (xor 16, xor 32).
-// No LDS: K/V of one (sample, head) are at most S*d*8 bytes and stay in L1/L2 across the waves that share them.
+// No LDS in this kernel (short sequences: K/V of one (sample, head) are a few KB and stay in L1/L2 across the waves that share
+// them); S >= 128 takes mha_core_lds_kernel below.
 #include "common.h"
 #include "kernels.h"
 
@@ -19,7 +20,7 @@ namespace {
 // KSPLIT = 1: one wave per 16-query block, all keys.  KSPLIT = 4: the 4 waves of a workgroup share one query block and take
 // the key blocks round-robin (4x shorter dependent load->MFMA->softmax chains at S >= 64); their (max, sum, O^T) partials
 // are merged through LDS with the usual online-softmax rescale.
-template <int D16, int KSPLIT>   // head dim = 16 * D16
+template <int D16, int KSPLIT>   // head dim d <= 16 * D16, d % 4 == 0 (missing quads of the last 16-block are read as zeros)
 __global__ __launch_bounds__(256) void mha_core_kernel(const float* __restrict__ qkv, float* __restrict__ out, int B,
                                                        int S, int C, int heads, float scale) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -32,7 +33,7 @@ __global__ __launch_bounds__(256) void mha_core_kernel(const float* __restrict__
     const int qb = w % qblocks; w /= qblocks;
     const int h = w % heads;
     const int b = w / heads;
-    const int d = 16 * D16;
+    const int d = C / heads;
     const size_t row_stride = 3 * (size_t)C;
     const float* base = qkv + (size_t)b * S * row_stride + (size_t)h * d;   // q of token 0; k at +C, v at +2C
 
@@ -42,8 +43,8 @@ __global__ __launch_bounds__(256) void mha_core_kernel(const float* __restrict__
     f32x4 qf[D16];
 #pragma unroll
     for (int j = 0; j < D16; ++j) {
-        qf[j] = q_ok ? *reinterpret_cast<const f32x4*>(base + (size_t)qi * row_stride + 16 * j + 4 * kq)
-                     : f32x4{0.f, 0.f, 0.f, 0.f};
+        qf[j] = (q_ok && 16 * j + 4 * kq < d) ? *reinterpret_cast<const f32x4*>(base + (size_t)qi * row_stride + 16 * j + 4 * kq)
+                                              : f32x4{0.f, 0.f, 0.f, 0.f};
         qf[j] *= scale;
     }
 
@@ -59,8 +60,8 @@ __global__ __launch_bounds__(256) void mha_core_kernel(const float* __restrict__
         f32x4 st = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < D16; ++j) {
-            const f32x4 kf = k_ok ? *reinterpret_cast<const f32x4*>(base + (size_t)krow * row_stride + C + 16 * j + 4 * kq)
-                                  : f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 kf = (k_ok && 16 * j + 4 * kq < d) ? *reinterpret_cast<const f32x4*>(base + (size_t)krow * row_stride + C + 16 * j + 4 * kq)
+                                                           : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int e = 0; e < 4; ++e) st = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[e], qf[j][e], st, 0, 0, 0);
         }
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(256) void mha_core_kernel(const float* __restrict__
             for (int e = 0; e < 4; ++e) {
                 // A operand: V^T[row = head-dim 16*j + r16][k = key k0 + 4*kq + e]
                 const int key = k0 + 4 * kq + e;
-                const float vv = key < S ? base[(size_t)key * row_stride + 2 * C + 16 * j + r16] : 0.f;
+                const float vv = (key < S && 16 * j + r16 < d) ? base[(size_t)key * row_stride + 2 * C + 16 * j + r16] : 0.f;
                 o[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv, st[e], o[j], 0, 0, 0);
             }
         }
@@ -127,7 +128,122 @@ __global__ __launch_bounds__(256) void mha_core_kernel(const float* __restrict__
         const float inv = 1.f / l_run;
         float* op = out + ((size_t)b * S + qi) * C + (size_t)h * d;
 #pragma unroll
-        for (int j = 0; j < D16; ++j) *reinterpret_cast<f32x4*>(op + 16 * j + 4 * kq) = o[j] * inv;
+        for (int j = 0; j < D16; ++j)
+            if (16 * j + 4 * kq < d) *reinterpret_cast<f32x4*>(op + 16 * j + 4 * kq) = o[j] * inv;
+    }
+}
+
+// ---- long sequences (S >= 128): K and V of one (sample, head) staged in LDS ----------------------------------------------------
+// The register kernel above re-reads K and V once per 16-query block straight from L2 (S/16 times per head; V as strided
+// dwords): at S = 256 it fetched 5.4x its qkv tensor.  Here a workgroup owns every `qsplit`-th query block of one (sample, head)
+// — up to NQ blocks per wave, their online-softmax state in registers — and walks the keys in chunks of KCH = 128 staged in LDS
+// with coalesced 16-byte loads, so K / V are fetched qsplit (2-8) times instead of S/16 times:
+//   K chunk  [key][16-dim unit][4 quads], unit stride odd and the quad rotated by key >> 1: the A fragments of S^T = K Q^T are
+//            conflict-free ds_read_b128;
+//   V chunk  [key][d + 4]: the A operand of O^T = V^T P^T needs 4 keys x 1 dim per lane = 4 ds_read_b32, conflict-free with the
+//            row stride = 4 (mod 8) floats (LDS time stays ~5 % of the MFMA time).
+constexpr int MHA_KCH = 128, MHA_NQ = 4;
+template <int D16>
+__global__ __launch_bounds__(256) void mha_core_lds_kernel(const float* __restrict__ qkv, float* __restrict__ out, int B, int S, int C,
+                                                           int heads, float scale, int qsplit) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int KU = D16 | 1;                               // 16-float units per key row (odd)
+    const int d = C / heads, VS = 16 * D16 + 4;
+    f32x4* Kl = reinterpret_cast<f32x4*>(smem_raw);           // [KCH][KU][4]
+    float* Vl = reinterpret_cast<float*>(Kl + MHA_KCH * KU * 4);   // [KCH][VS]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, kq = lane >> 4;
+    int w = blockIdx.x;
+    const int qs = w % qsplit; w /= qsplit;
+    const int h = w % heads;
+    const int b = w / heads;
+    const int qblocks = (S + 15) >> 4;
+    const size_t row_stride = 3 * (size_t)C;
+    const float* base = qkv + (size_t)b * S * row_stride + (size_t)h * d;
+
+    // this wave's query blocks: qb = qs + qsplit * (wave + 4 n)
+    f32x4 qf[MHA_NQ][D16], o[MHA_NQ][D16];
+    float m_run[MHA_NQ], l_run[MHA_NQ];
+#pragma unroll
+    for (int n = 0; n < MHA_NQ; ++n) {
+        const int qi = (qs + qsplit * (wave + 4 * n)) * 16 + r16;
+        m_run[n] = -INFINITY; l_run[n] = 0.f;
+#pragma unroll
+        for (int j = 0; j < D16; ++j) {
+            o[n][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            qf[n][j] = (qi < S && 16 * j + 4 * kq < d) ? *reinterpret_cast<const f32x4*>(base + (size_t)qi * row_stride + 16 * j + 4 * kq)
+                                                       : f32x4{0.f, 0.f, 0.f, 0.f};
+            qf[n][j] *= scale;
+        }
+    }
+    const int uq = 4 * D16;                                   // quads per (zero-padded) key row
+    for (int c0 = 0; c0 < S; c0 += MHA_KCH) {
+        __syncthreads();                                      // every wave is done with the previous chunk
+        for (int i = tid; i < MHA_KCH * uq; i += 256) {
+            const int key = i / uq, q4 = i - key * uq;
+            const bool ok = c0 + key < S && 4 * q4 < d;
+            const float* src = base + (size_t)(c0 + key) * row_stride + 4 * q4;
+            const f32x4 kv = ok ? *reinterpret_cast<const f32x4*>(src + C) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const f32x4 vv = ok ? *reinterpret_cast<const f32x4*>(src + 2 * C) : f32x4{0.f, 0.f, 0.f, 0.f};
+            Kl[(key * KU + (q4 >> 2)) * 4 + (((q4 & 3) + (key >> 1)) & 3)] = kv;
+            *reinterpret_cast<f32x4*>(Vl + key * VS + 4 * q4) = vv;
+        }
+        __syncthreads();
+        const int kend = min(MHA_KCH, S - c0);
+#pragma unroll
+        for (int n = 0; n < MHA_NQ; ++n) {
+            if ((qs + qsplit * (wave + 4 * n)) >= qblocks) break;           // wave-uniform
+            for (int kl = 0; kl < kend; kl += 16) {
+                f32x4 st = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < D16; ++j) {
+                    const f32x4 kf = Kl[((kl + r16) * KU + j) * 4 + ((kq + ((kl + r16) >> 1)) & 3)];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) st = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[e], qf[n][j][e], st, 0, 0, 0);
+                }
+                float mx = -INFINITY;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (c0 + kl + 4 * kq + e >= S) st[e] = -INFINITY;
+                    mx = fmaxf(mx, st[e]);
+                }
+                mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+                mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+                const float m_new = fmaxf(m_run[n], mx);
+                const float alpha = expf(m_run[n] - m_new);
+                float ps = 0.f;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    st[e] = expf(st[e] - m_new);
+                    ps += st[e];
+                }
+                ps += __shfl_xor(ps, 16, 64);
+                ps += __shfl_xor(ps, 32, 64);
+                l_run[n] = l_run[n] * alpha + ps;
+                m_run[n] = m_new;
+#pragma unroll
+                for (int j = 0; j < D16; ++j) {
+                    o[n][j] *= alpha;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float vv = Vl[(kl + 4 * kq + e) * VS + 16 * j + r16];
+                        o[n][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv, st[e], o[n][j], 0, 0, 0);
+                    }
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int n = 0; n < MHA_NQ; ++n) {
+        const int qi = (qs + qsplit * (wave + 4 * n)) * 16 + r16;
+        if (qi < S) {
+            const float inv = 1.f / l_run[n];
+            float* op = out + ((size_t)b * S + qi) * C + (size_t)h * d;
+#pragma unroll
+            for (int j = 0; j < D16; ++j)
+                if (16 * j + 4 * kq < d) *reinterpret_cast<f32x4*>(op + 16 * j + 4 * kq) = o[n][j] * inv;
+        }
     }
 }
 
@@ -136,13 +252,31 @@ __global__ __launch_bounds__(256) void mha_core_kernel(const float* __restrict__
 int sbgm_launch_mha_core(const float* qkv, float* out, int B, int S, int C, int heads, hipStream_t st) {
     SBGM_CHECK(heads > 0 && C % heads == 0, "mha: C=%d not divisible by heads=%d", C, heads);
     const int d = C / heads;
-    SBGM_CHECK(d % 16 == 0 && d <= 512, "mha: head dim %d must be a multiple of 16 (<= 512)", d);
+    SBGM_CHECK(d % 4 == 0 && d <= 512, "mha: head dim %d must be a multiple of 4 (<= 512)", d);
+    const int d16 = (d + 15) / 16;
+    const float scale = 1.0f / sqrtf((float)d);
+    static const bool lds_ok = getenv("SBGM_NO_LDS_ATTENTION") == nullptr;
+    if (lds_ok && S >= 128 && d16 <= 4) {
+        // query blocks of one (sample, head) are dealt to `qsplit` workgroups: enough of them for ~2 per CU, at most 16 blocks each
+        const int qblocks = (S + 15) / 16, bh = B * heads;
+        int qsplit = std::max((512 + bh - 1) / bh, (qblocks + 4 * MHA_NQ - 1) / (4 * MHA_NQ));
+        qsplit = std::max(1, std::min(qsplit, qblocks));
+        const size_t lds = (size_t)MHA_KCH * (d16 | 1) * 64 + (size_t)MHA_KCH * (16 * d16 + 4) * 4;
+        const dim3 grid(bh * qsplit), block(256);
+        switch (d16) {
+            case 1: hipLaunchKernelGGL((mha_core_lds_kernel<1>), grid, block, lds, st, qkv, out, B, S, C, heads, scale, qsplit); break;
+            case 2: hipLaunchKernelGGL((mha_core_lds_kernel<2>), grid, block, lds, st, qkv, out, B, S, C, heads, scale, qsplit); break;
+            case 3: hipLaunchKernelGGL((mha_core_lds_kernel<3>), grid, block, lds, st, qkv, out, B, S, C, heads, scale, qsplit); break;
+            default: hipLaunchKernelGGL((mha_core_lds_kernel<4>), grid, block, lds, st, qkv, out, B, S, C, heads, scale, qsplit); break;
+        }
+        SBGM_LAUNCH_CHECK();
+        return 0;
+    }
     const int waves = B * heads * ((S + 15) / 16);
     const bool ksplit = S >= 64 && d <= 256;             // >= 4 key blocks: spread them over the 4 waves of a workgroup
     const dim3 grid(ksplit ? waves : (waves + 3) / 4), block(256);
-    const size_t lds = ksplit ? (size_t)4 * 64 * 2 * 4 + (size_t)4 * (d / 16) * 64 * 16 : 0;
-    const float scale = 1.0f / sqrtf((float)d);
-    switch (d / 16) {
+    const size_t lds = ksplit ? (size_t)4 * 64 * 2 * 4 + (size_t)4 * d16 * 64 * 16 : 0;
+    switch (d16) {
 #define SBGM_MHA(N)                                                                                                      \
     case N:                                                                                                              \
         if (ksplit) hipLaunchKernelGGL((mha_core_kernel<N, 4>), grid, block, lds, st, qkv, out, B, S, C, heads, scale);    \

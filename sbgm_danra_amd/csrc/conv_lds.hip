@@ -276,18 +276,31 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(const ConvParams p) {
                         v[3][j] = 0.25f * xa + up_b3 * xb + up_c3 * xc;
                     }
                 }
+                if (FCO * FPX == 1) {
+                    // one accumulator per xi: sweep k outermost so consecutive MFMAs go to the 4 DIFFERENT xi accumulators (a lone
+                    // accumulator chain pays the 40-cycle dependent latency instead of the 32-cycle issue rate)
+                    f32x4 a4[4];
 #pragma unroll
-                for (int xi = 0; xi < 4; ++xi) {
-                    f32x4 a[FCO];
-#pragma unroll
-                    for (int i = 0; i < FCO; ++i) a[i] = wl[((kh * 4 + xi) * NCO + 16 * i) * 4 + swz(r16, kq)];
+                    for (int xi = 0; xi < 4; ++xi) a4[xi] = wl[((kh * 4 + xi) * NCO) * 4 + swz(r16, kq)];
 #pragma unroll
                     for (int k = 0; k < 4; ++k)
 #pragma unroll
-                        for (int i = 0; i < FCO; ++i)
+                        for (int xi = 0; xi < 4; ++xi)
+                            acc[xi][0][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4[xi][k], v[xi][0][k], acc[xi][0][0], 0, 0, 0);
+                } else {
 #pragma unroll
-                            for (int j = 0; j < FPX; ++j)
-                                acc[xi][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][k], v[xi][j][k], acc[xi][i][j], 0, 0, 0);
+                    for (int xi = 0; xi < 4; ++xi) {
+                        f32x4 a[FCO];
+#pragma unroll
+                        for (int i = 0; i < FCO; ++i) a[i] = wl[((kh * 4 + xi) * NCO + 16 * i) * 4 + swz(r16, kq)];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k)
+#pragma unroll
+                            for (int i = 0; i < FCO; ++i)
+#pragma unroll
+                                for (int j = 0; j < FPX; ++j)
+                                    acc[xi][i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[i][k], v[xi][j][k], acc[xi][i][j], 0, 0, 0);
+                    }
                 }
             }
         }

@@ -139,7 +139,8 @@ def test_act_upsample_backward():
 
 
 @pytest.mark.parametrize("B,S,Cc,heads", [(2, 64, 256, 4), (1, 16, 512, 4), (1, 256, 128, 4), (2, 4, 256, 2), (1, 40, 128, 1),
-                                          (1, 1024, 128, 4)])      # the last one exceeds the LDS-staged variant: scalar fallback
+                                          (1, 1024, 128, 4),       # exceeds the LDS-staged variant: scalar fallback
+                                          (2, 64, 128, 16), (1, 144, 96, 8)])      # head dims 8 and 12 (num_heads = 16 of the reference's sweep)
 def test_mha_core_backward(B, S, Cc, heads):
     qkv, go = rnd(B * S, 3 * Cc), rnd(B * S, Cc, seed=1)
     d = Cc // heads

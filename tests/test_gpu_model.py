@@ -296,3 +296,23 @@ def test_pc_sampler_with_train_mode_batchnorm_matches_reference_golden(golden_di
     assert maxrel(sd["encoder.bn1.running_var"].cpu(), g["bn1_running_var"]) <= 1e-4
     assert maxrel(sd["encoder.layer4.1.bn2.running_var"].cpu(), g["l4_running_var"]) <= 1e-3
     assert int(sd["encoder.bn1.num_batches_tracked"]) == int(g["num_batches_tracked"]) == 4      # 2 steps x 2 evaluations
+
+
+def test_sixteen_heads_from_the_reference_sweep_space():
+    """num_heads = 16 (reference sweep/run_optuna.py:124-131) gives head dims 8 / 16 / 32 on the 128- / 256- / 512-channel attention
+    blocks: forward vs the oracle and the attention parameters' gradients (head dim 8 goes through the generic-dim paths)"""
+    import sbgm_danra_amd as S
+    from oracle import torch_ref as O
+    ora, net, _ = build_pair(1, heads=16)
+    g = torch.Generator().manual_seed(16)
+    x, c, t = torch.randn(2, 1, 64, 64, generator=g) * 5, torch.randn(2, 1, 64, 64, generator=g), torch.tensor([0.3, 0.8])
+    ora.eval(), net.eval()
+    with torch.no_grad():
+        assert maxrel(net(x.cuda(), t.cuda(), cond_img=c.cuda()).cpu(), ora(x, t, cond_img=c)) <= TOL
+    ora.train(), net.train()
+    z = torch.randn(2, 1, 64, 64, generator=g)
+    O.loss_fn(ora, x, O.marginal_prob_std_fn, cond_img=c, noise=(t, z)).backward()
+    S.loss_fn(net, x.cuda(), S.marginal_prob_std_fn, cond_img=c.cuda(), noise=(t.cuda(), z.cuda())).backward()
+    po, pn = dict(ora.named_parameters()), dict(net.named_parameters())
+    worst = max(maxrel(pn[k].grad.cpu(), po[k].grad) for k in po if ".attention" in k or ".mha." in k)
+    assert worst < 1e-4, worst

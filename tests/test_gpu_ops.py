@@ -283,7 +283,9 @@ def test_batchnorm_train(with_res):
 
 
 @pytest.mark.parametrize("B,S,C_,heads", [(2, 64, 256, 4), (2, 16, 512, 4), (1, 256, 128, 4), (3, 4, 256, 2), (1, 1024, 128, 8),
-                                          (2, 40, 128, 1), (2, 88, 128, 2), (1, 200, 96, 2)])
+                                          (2, 40, 128, 1), (2, 88, 128, 2), (1, 200, 96, 2),
+                                          (32, 256, 128, 4), (2, 1024, 128, 4), (3, 300, 64, 2), (1, 130, 256, 4),     # LDS-staged K/V (S >= 128), ragged S
+                                          (2, 64, 128, 16), (1, 256, 128, 16), (2, 40, 96, 4), (1, 144, 48, 4)])      # head dims 8, 24, 12 (d % 4 == 0)
 def test_mha_core(B, S, C_, heads):
     qkv = rnd(B, S, 3 * C_)
     d = C_ // heads
