@@ -258,8 +258,9 @@ def test_errors_are_loud():
 
 def test_ode_sampler_matches_reference_golden(golden_dir):
     """ode_sampler (reference score_sampling.py:239-300): scipy RK45 around native network evaluations, start z injected.
-    The solver's step control reacts to fp32-level differences of the right-hand side, so the endpoint is compared at 1e-3
-    and the evaluation count within 2 % (golden: 974 evaluations at rtol = atol = 1e-5, 224 at 1e-3)."""
+    The adaptive solver amplifies fp32-level differences of the right-hand side up to its own tolerance, so the endpoint is held to
+    20 x the solver tolerance (measured: 1.6e-5 at rtol = atol = 1e-5, 5e-4 .. 4e-3 at 1e-3, depending on the convolution tiles'
+    summation order) and the evaluation count to 2 % (golden: 974 evaluations at 1e-5, 224 at 1e-3)."""
     import sbgm_danra_amd as S
     g = load_golden(os.path.join(golden_dir, "ode_b2_32.npz"))
     _, net, _ = build_pair(0)
@@ -271,7 +272,7 @@ def test_ode_sampler_matches_reference_golden(golden_dir):
         err = maxrel(got.cpu(), want)
         print(f"ode_sampler {tag}: max-rel {err:.2e}, nfev {nfev} (reference {nref})")
         assert got.dtype == torch.float64 and got.shape == (2, 1, 32, 32)       # res.y is float64 in the reference too (:297)
-        assert err <= 1e-3 and abs(nfev - nref) <= max(6, 0.02 * nref)
+        assert err <= 20 * tol and abs(nfev - nref) <= max(6, 0.02 * nref)
     # default start: 32x32 draws scaled by marginal_prob_std(1), like the reference (:279-281)
     torch.manual_seed(3)
     out = S.ode_sampler(net, S.marginal_prob_std_fn, S.diffusion_coeff_fn, batch_size=1, device="cuda", atol=1e-2, rtol=1e-2)
