@@ -59,12 +59,17 @@ def spawn_ranks(n, argv):
     return max(abs(rc) for rc in rcs)
 
 
-def git_head():
-    try:
-        import subprocess
-        return subprocess.run(["git", "-C", ROOT, "rev-parse", "--short=12", "HEAD"], capture_output=True, text=True, timeout=10).stdout.strip()
-    except Exception:
-        return ""
+def kernel_source_hash():
+    """sha256 over the kernel sources + the C-ABI header (16 hex digits).  The PMC traffic files under profiles/ record the hash
+    of the tree they were measured on; a file measured on other kernels is refused (the GPU box has no .git to ask for HEAD)."""
+    import hashlib
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "sbgm_danra_amd", "csrc")
+    files = sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".h", ".cpp")))
+    for f in files + [os.path.join(ROOT, "include", "sbgm_hip.h")]:
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
 
 
 def build_model(dev, n_cond=1):
@@ -115,6 +120,89 @@ def cpu_baseline(batch, hw, budget_s=20.0):
     return {"value": batch * n / dt, "unit": "denoising steps/s", "cores": cores, "kind": "port",
             "sample": f"{n} Euler-Maruyama steps of the CPU oracle at batch {batch}, {hw}x{hw}, after 1 warm-up "
                       f"({dt:.1f} s, PyTorch-CPU {torch.__version__}, {model})"}
+
+
+def train_secondary(dev, steps=10, warmup=3):
+    """C3 per-GPU training step (128x128, 4 conditions, batch 8): loss_fn forward + native backward replayed as one hipGraph + the
+    native Adam step, timed like the headline; plus the roofline of the weight-gradient kernel family — every convolution /
+    linear weight gradient of the step re-launched in isolation (10 launches in one graph, HIP events) on the step's own shapes."""
+    import sbgm_danra_amd as S
+    from sbgm_danra_amd import _native as N
+    from sbgm_danra_amd import train_graph as T
+    net = build_model(dev, n_cond=4)
+    net.train()
+    opt = S.optim.Adam(net.parameters(), lr=5e-4, weight_decay=1e-6)
+    B, HW = 8, 128
+    g = torch.Generator().manual_seed(42)
+    x, cond = torch.randn(B, 1, HW, HW, generator=g).to(dev), torch.randn(B, 4, HW, HW, generator=g).to(dev)
+
+    def fwd_bwd():
+        loss = S.loss_fn(net, x, S.marginal_prob_std_fn, cond_img=cond)
+        loss.backward()
+        return loss
+    T._WGRAD_LOG[0] = []
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for i in range(3):
+            opt.zero_grad(set_to_none=True)
+            fwd_bwd()
+            opt.step()
+            if i == 0:
+                geoms, T._WGRAD_LOG[0] = T._WGRAD_LOG[0], None
+    torch.cuda.current_stream().wait_stream(side)
+    graph = torch.cuda.CUDAGraph()
+    opt.zero_grad(set_to_none=True)
+    with torch.cuda.graph(graph):
+        loss = fwd_bwd()
+    for _ in range(warmup):
+        graph.replay()
+        opt.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        graph.replay()
+        opt.step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    # ---- weight-gradient family, isolated launches ------------------------------------------------------------------------------
+    lib, tot_us, tot_fl, rows = N.lib(), 0.0, 0.0, []
+    for (Bq, H, W, cs, cin, cout, k, stride, pad) in geoms:
+        oh, ow = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        dy, xx = torch.randn(Bq, oh, ow, cout, device=dev), torch.randn(Bq, H, W, cs, device=dev)
+        dw, ws = torch.empty(cout, cin, k, k, device=dev), torch.zeros(k * k * cout * cs, device=dev)
+
+        def launch():
+            N.check(lib.sbgm_conv2d_wgrad(dy.data_ptr(), xx.data_ptr(), dw.data_ptr(), ws.data_ptr(), Bq, H, W, cs, cin, cout, k, k, stride, pad,
+                                          N.stream()))
+        launch()
+        gg = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gg):
+            for _ in range(10):
+                launch()
+        gg.replay()
+        e0, e1 = torch.cuda.Event(True), torch.cuda.Event(True)
+        torch.cuda.synchronize()
+        e0.record()
+        gg.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / 10
+        fl = 2.0 * Bq * oh * ow * cin * cout * k * k
+        tot_us += us
+        tot_fl += fl
+        rows.append({"B": Bq, "H": H, "W": W, "Cin": cin, "Cout": cout, "k": k, "stride": stride, "us": us, "tflops": fl / us * 1e-6})
+    ach = tot_fl / tot_us * 1e-6
+    rows.sort(key=lambda r: -r["us"])
+    return {"metric": "training samples/sec at 128x128 (loss_fn forward + backward as one hipGraph + native Adam), 1 GPU",
+            "value": B * steps / dt, "unit": "samples/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+            "workload": "128x128 4-cond->1-target (C_in=5), batch 8 per GPU (BASELINE configs[2] per-GPU shape)",
+            "final_loss": float(loss.detach()), "fp32_frac_of_step": 3 * 5.247e9 * B / (dt / steps) / (PEAK_FP32_TFLOPS * 1e12),
+            "wgrad_roofline": {"bound": "mfma", "kernel": "conv weight-gradient family (conv3x3_wgrad_lds / conv_tap_wgrad_lds / conv_wgrad + layout pass)",
+                               "launches_per_step": len(geoms), "sum_us": tot_us, "gflop": tot_fl * 1e-9, "achieved": ach,
+                               "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS,
+                               "note": "each weight gradient of the step re-launched alone (10 per graph, HIP events); includes its zero-fill and OIHW layout pass",
+                               "slowest": rows[:5]}}
 
 
 def train_bench(a):
@@ -265,6 +353,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-autotune", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the C3 training-step measurement appended to the default line")
     ap.add_argument("--tune-cache", default=None, help="tile-table file: loaded when present, else written after autotuning "
                                                        "(lets the rocprofv3 passes replay exactly the benchmarked kernels)")
     ap.add_argument("--profile-csv", default=None, help="write the per-convolution event timings here")
@@ -326,6 +415,15 @@ def main():
         tt = torch.tensor([dt], device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
+    # the same K-step loop twice more (reported beside the headline, which stays the FIRST timed loop): at K = 20 the timed region is
+    # ~35 ms, so one number alone says little about its own spread
+    repeats = [dt]
+    for _ in range(2):
+        barrier()
+        t1 = time.perf_counter()
+        sampler(net, S.marginal_prob_std_fn, S.diffusion_coeff_fn, num_steps=a.steps, **kw)
+        barrier()
+        repeats.append(time.perf_counter() - t1)
 
     roof, cpu = None, None
     if rank == 0:
@@ -385,19 +483,27 @@ def main():
                "gflop_per_launch": df["gflop"] / df["launches"], "tflops": df["gflop"] / df["us"] * 1e3,
                "alg_bytes_per_launch": df["bytes"] / df["launches"], "executed_flop_ratio": df["exec"] / df["gflop"],
                "instantiations": df["inst"]}
-        # HBM-side traffic of that kernel: PMC counters cannot be read from inside this process; they come from the
-        # separately collected rocprofv3 passes (tools/collect_profiles.sh -> profiles/r01_pmc_traffic.json), if committed
+        # HBM-side traffic of that kernel: PMC counters cannot be read from inside this process; they come from the separately
+        # collected rocprofv3 passes of THIS workload (tools/collect_profiles.sh -> profiles/<round>_pmc_traffic_<workload>.json).
+        # A file measured on other kernel sources (source_hash) is refused: traffic = null with the reason.
         traffic, traffic_src = None, None
-        for tag in ("r06", "r05", "r04", "r03", "r02", "r01"):
-            tp = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic.json")
-            if os.path.exists(tp):
-                with open(tp) as f:
-                    tk = json.load(f)["kernels"]
-                ents = [(v["bytes_per_launch"], v["launches"]) for n, v in tk.items() if n.split("<")[0] == dname]
-                if ents and B == 32 and HW == 128:
-                    traffic = sum(b * n for b, n in ents) / sum(n for _, n in ents)
-                    traffic_src = f"profiles/{tag}_pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, launch-weighted over the instantiations)"
+        wl = f"b{B}_{HW}_{a.sampler}"
+        for tag in ("r06", "r05", "r04", "r03", "r02"):
+            tp = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic_{wl}.json")
+            if not os.path.exists(tp):
+                continue
+            with open(tp) as f:
+                tj = json.load(f)
+            if tj.get("source_hash") != kernel_source_hash():
+                traffic_src = f"refused profiles/{tag}_pmc_traffic_{wl}.json: measured on kernel sources {tj.get('source_hash')}, this tree is {kernel_source_hash()}"
                 break
+            ents = [(v["bytes_per_launch"], v["launches"]) for n, v in tj["kernels"].items() if n.split("<")[0] == dname]
+            if ents:
+                traffic = sum(b * n for b, n in ents) / sum(n for _, n in ents)
+                traffic_src = f"profiles/{tag}_pmc_traffic_{wl}.json (2*FETCH_SIZE + WRITE_SIZE per launch, launch-weighted over the instantiations; same kernel sources)"
+            break
+        if traffic_src is None:
+            traffic_src = f"no profiles/*_pmc_traffic_{wl}.json for this workload"
         ach = fl_conv / (ms_conv * 1e-3) * 1e-12
         ms_eval = dt / (a.steps * evals_per_step) * 1e3
         flops_eval = FLOP_PER_SAMPLE_128 * B * (HW / 128.0) ** 2
@@ -421,6 +527,15 @@ def main():
                                "hbm_frac_layer_fused_bytes": BYTES_PER_EVAL(B, HW) / (ms_eval * 1e-3) / (PEAK_HBM_GBS * 1e9)}}
         if not a.no_cpu_baseline and world == 1:                   # the CPU reference leg is reported at N=1 only
             cpu = cpu_baseline(B, HW)
+    secondary = None
+    if rank == 0 and world == 1 and not a.no_secondary and B == 32 and HW == 128:
+        # BASELINE configs[2] beside the headline, so the training step is driver-timed too: per-GPU shape (batch 8, C_in = 5)
+        del net, out, cond
+        torch.cuda.empty_cache()
+        try:
+            secondary = {"train_c3": train_secondary(dev)}
+        except Exception as e:                                     # never lose the headline line to the secondary measurement
+            secondary = {"train_c3": {"error": f"{type(e).__name__}: {e}"}}
 
     if rank == 0:
         value = B * a.steps * world / dt
@@ -431,8 +546,11 @@ def main():
                                        f"{'Euler-Maruyama' if a.sampler == 'em' else 'predictor-corrector'} sampling, "
                                        f"{evals_per_step} network eval/step, hipGraph={'off' if a.no_graph else 'on'}",
                            "global_batch": B * world, "sampler": a.sampler, "network_evals_per_s": value * evals_per_step,
+                           "repeat_ms_per_step": {"runs": [r / a.steps * 1e3 for r in repeats], "min": min(repeats) / a.steps * 1e3,
+                                                  "median": sorted(repeats)[1] / a.steps * 1e3,
+                                                  "note": "3 consecutive timed loops of the same K steps; ms_per_step / value are the first"},
                            "parallelism": f"dp{world} (independent batches, no collective)"},
-                "roofline": roof, "cpu_baseline": cpu}
+                "roofline": roof, "cpu_baseline": cpu, "secondary": secondary}
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -33,12 +33,14 @@ FMAP_CHANNELS = [64, 64, 128, 256, 512]          # reference score_unet.py:198
 # parameter containers (same attribute names as the reference / torchvision -> same state_dict keys)
 # --------------------------------------------------------------------------------------------------------------
 class _NativeOnly(nn.Module):
-    """Sub-modules hold parameters; evaluation goes through ScoreNet (whole-network engine)."""
+    """Sub-modules hold parameters; inside a ScoreNet the whole-network engine evaluates them.  Encoder, DecoderBlock and Decoder
+    can also be called on their own like the reference's modules (NCHW tensors in and out): those calls run the same native
+    kernels op by op (train_graph.py), with autograd in train() mode.  The leaf containers have no stand-alone forward."""
 
     def forward(self, *a, **k):
         raise NotImplementedError(
-            f"{type(self).__name__} is evaluated by the native engine through ScoreNet.forward(); "
-            "stand-alone sub-module calls are not part of the accelerated path")
+            f"{type(self).__name__} is evaluated by the native kernels through ScoreNet / Encoder / DecoderBlock / Decoder; "
+            "it has no stand-alone forward")
 
 
 class SinusoidalEmbedding(_NativeOnly):
@@ -124,6 +126,11 @@ class Encoder(_NativeOnly):
             with torch.no_grad():
                 self.label_emb.weight[0].fill_(0.0)       # null class (reference :224-226)
 
+    def forward(self, x, t, y=None, cond_img=None, lsm_cond=None, topo_cond=None):
+        """-> (fmap1 .. fmap5), NCHW (reference score_unet.py:247-364)"""
+        from .train_graph import encoder_call
+        return encoder_call(self, x, t, y, cond_img, lsm_cond, topo_cond)
+
     def make_time_projections(self, fmap_channels: Iterable[int]):
         return nn.ModuleList([nn.Sequential(nn.SiLU(), nn.Linear(self.time_embedding, ch)) for ch in fmap_channels])
 
@@ -169,6 +176,12 @@ class DecoderBlock(_NativeOnly):
         self.time_projection_layer = nn.Sequential(nn.SiLU(), nn.Linear(time_embedding, output_channels))
         self.attention = ImageSelfAttention(output_channels, n_heads) if compute_attn else nn.Identity()
 
+    def forward(self, fmap, prev_fmap=None, t=None):
+        """upsample -> conv_up -> norm1 -> conv -> norm2 -> +prev_fmap -> +time -> activation -> [attention]; `t` is the time
+        vector [B] (reference score_unet.py:559-627)"""
+        from .train_graph import decoder_block_call
+        return decoder_block_call(self, fmap, prev_fmap, t)
+
 
 class Decoder(_NativeOnly):
     """Four DecoderBlocks (attention on the first two) and a norm-free, activation-free final block
@@ -190,6 +203,12 @@ class Decoder(_NativeOnly):
         self.final_layer.norm1 = nn.Identity()            # reference :726-730
         self.final_layer.norm2 = nn.Identity()
         self.final_layer.activation = nn.Identity()
+
+    def forward(self, *fmaps, t=None):
+        """fmaps = (fmap1 .. fmap5) in encoder order -> final_layer output [B,1,H,W], before the division by sigma(t)
+        (reference score_unet.py:733-758)"""
+        from .train_graph import decoder_call
+        return decoder_call(self, *fmaps, t=t)
 
     def make_layers(self, n: int = 4):
         layers = []

@@ -101,6 +101,7 @@ class GradArena:
         return self.flat[off: off + n].view(p.shape)
 
 
+_WGRAD_LOG = [None]             # bench.py: when a list, ConvFn.backward appends the geometry of every weight gradient it launches
 _ACTIVE_ARENA = [None]
 _USE_ARENA = [True]             # debugging switch: False = every gradient in a fresh tensor (the pre-arena behaviour)
 
@@ -320,6 +321,8 @@ class ConvFn(torch.autograd.Function):
             _conv_launch(dy, packed, dx, cout, cin, k, 1, k - 1 - pad, in_dil=2 if stride == 2 else 0, out_hw=(H, W))
         want_db = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
+            if _WGRAD_LOG[0] is not None:
+                _WGRAD_LOG[0].append((B, H, W, cs, cin, cout, k, stride, pad))
             if k == 1 and cs == cin and cs % 64 == 0 and cout % 64 == 0:
                 # 1x1 / linear: the partial-sum slab has the OIHW layout, so the (zeroed) gradient itself is the workspace
                 dw, pooled = _pgrad(arena, w, True)
@@ -605,7 +608,7 @@ class TimeProjFn(torch.autograd.Function):
 
 
 class Cout1Fn(torch.autograd.Function):
-    """final_layer.conv (3x3, C -> 1) followed by the division by sigma(t): NHWC a -> NCHW [B,1,H,W]"""
+    """final_layer.conv (3x3, C -> 1) followed by the division by sigma(t) (t None: no division): NHWC a -> NCHW [B,1,H,W]"""
 
     @staticmethod
     def forward(ctx, a, w, bias, t, sigma):
@@ -613,7 +616,7 @@ class Cout1Fn(torch.autograd.Function):
         wp = torch.empty(9 * Cc, device=a.device)
         N.check(_L().sbgm_cout1_pack_weight(w.data_ptr(), wp.data_ptr(), Cc, _st()))
         out = torch.empty(B, 1, H, W, device=a.device)
-        N.check(_L().sbgm_conv3x3_cout1_fwd(a.data_ptr(), wp.data_ptr(), bias.data_ptr(), t.data_ptr(), sigma, out.data_ptr(), B, H, W, Cc,
+        N.check(_L().sbgm_conv3x3_cout1_fwd(a.data_ptr(), wp.data_ptr(), bias.data_ptr(), N.ptr(t), sigma, out.data_ptr(), B, H, W, Cc,
                                             _st()))
         ctx.save_for_backward(a, wp, t, w, bias)
         ctx.sigma = sigma
@@ -626,7 +629,7 @@ class Cout1Fn(torch.autograd.Function):
         dout = dout.contiguous()
         B, H, W, Cc = a.shape
         da, dwp, db = torch.empty_like(a), torch.empty(9 * Cc, device=a.device), _pgrad(ctx.arena, bias, False)[0]
-        N.check(_L().sbgm_conv3x3_cout1_bwd(dout.data_ptr(), a.data_ptr(), wp.data_ptr(), t.data_ptr(), ctx.sigma, da.data_ptr(),
+        N.check(_L().sbgm_conv3x3_cout1_bwd(dout.data_ptr(), a.data_ptr(), wp.data_ptr(), N.ptr(t), ctx.sigma, da.data_ptr(),
                                             dwp.data_ptr(), db.data_ptr(), B, H, W, Cc, _st()))
         dw, _ = _pgrad(ctx.arena, w, False)
         dw.view(Cc, 9).copy_(dwp.view(9, Cc).t())                                        # [tap][c] -> OIHW
@@ -650,8 +653,28 @@ _NBT = []
 
 
 def _bn(x, bn, res=None, tb_after=None, relu=True):
+    if not bn.training:
+        return _bn_eval(x, bn, res, tb_after, relu)
     y = BNTrainFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, res, tb_after, relu, bn.eps, bn.momentum)
     _NBT.append(bn.num_batches_tracked)                  # incremented together at the end of forward_train (one launch, not 20)
+    return y
+
+
+def _bn_eval(x, bn, res, tb_after, relu):
+    """BatchNorm2d with running statistics (module.eval()), for stand-alone sub-module calls under no_grad: the apply half of the
+    train-mode kernel, fed sums that reproduce (running_mean, running_var) exactly, running statistics left untouched."""
+    if torch.is_grad_enabled() and (x.requires_grad or bn.weight.requires_grad):
+        raise NotImplementedError("gradients through an eval()-mode (running-statistics BatchNorm) network are not implemented; "
+                                  "call .train() or evaluate under torch.no_grad()")
+    B, H, W, Cc = x.shape
+    n = float(B * H * W)
+    rm, rv = bn.running_mean.double(), bn.running_var.double()
+    sums = torch.stack([rm * n, (rv + rm * rm) * n], 1).contiguous()            # [C][2] fp64: (sum x, sum x^2)
+    ws = torch.empty(3 * Cc, dtype=torch.float64, device=x.device)              # sums + the (mean, rstd) pairs behind them
+    ws[:2 * Cc] = sums.view(-1)
+    y = torch.empty_like(x)
+    N.check(_L().sbgm_batchnorm_train_apply(x.data_ptr(), y.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), None, None, N.ptr(res),
+                                            N.ptr(tb_after), int(relu), B, H * W, Cc, bn.eps, 0.0, ws.data_ptr(), n, None, _st()))
     return y
 
 
@@ -689,29 +712,34 @@ def forward_train(net, x, t, y, cond, lsm, topo):
         _SYNC_COUNT[0] = int(round(float(cnt.item())))
     plan.run(x.device)
     try:
-        return _forward_train(net, x, t, y, cond, lsm, topo)
+        fmaps = encoder_forward(net.encoder, x, t, y, cond, lsm, topo)
+        a = decoder_forward(net.decoder, fmaps, t)
+        fin = net.decoder.final_layer
+        _bump_nbt()
+        return Cout1Fn.apply(a, fin.conv.weight, fin.conv.bias, t, float(net.sigma))
     finally:
         _ACTIVE_PLAN[0] = None
         _ACTIVE_ARENA[0] = None
 
 
-def _forward_train(net, x, t, y, cond, lsm, topo):
-    enc, dec = net.encoder, net.decoder
-    sigma = float(net.sigma)
+def _bump_nbt():
+    if _NBT:
+        with torch.no_grad():
+            torch._foreach_add_(list(_NBT), 1)
+        _NBT.clear()
 
-    def upsampled(blk, h):        # (A) of DecoderBlock: resize-conv (default) or the ConvTranspose2d ablation path
-        if dec.use_resize_conv:
-            return ConvFn.apply(UpsampleFn.apply(h), blk.conv_up.weight, blk.conv_up.bias, None, None, 1, 1)
-        return conv_transpose2x(h, blk.transpose)
+
+def _tproj(t, y, tlabel, freq_mod, seq):
+    return TimeProjFn.apply(t, y, tlabel, freq_mod.W, seq[1].weight, seq[1].bias)
+
+
+def encoder_forward(enc, x, t, y, cond, lsm, topo):
+    """Encoder.forward (reference score_unet.py:247-364) on NCHW inputs -> the 5 feature maps, NHWC"""
     tlabel = enc.label_emb.weight if (y is not None and enc.num_classes is not None) else None
     if y is not None and tlabel is None:
         raise ValueError("y given but the model has no label embedding")
-
-    def tproj(freq_mod, seq, with_label):
-        return TimeProjFn.apply(t, y if with_label else None, tlabel if with_label else None, freq_mod.W, seq[1].weight, seq[1].bias)
-
     x0 = _pack_inputs(x, lsm, topo, cond, _pad_c(enc.input_channels))
-    tb = [tproj(enc.sinusoidal_embedding, enc.time_projection_layers[i], y is not None) for i in range(5)]
+    tb = [_tproj(t, y if tlabel is not None else None, tlabel, enc.sinusoidal_embedding, enc.time_projection_layers[i]) for i in range(5)]
     f1 = ConvFn.apply(x0, enc.conv1.weight, None, None, tb[0], 2, 3)                    # conv1 + time bias (:312-316)
     h = _bn(ConvFn.apply(f1, enc.conv2.weight, None, None, None, 2, 3), enc.bn1)
     fmaps = [f1]
@@ -727,24 +755,127 @@ def _forward_train(net, x, t, y, cond, lsm, topo):
         if not isinstance(enc.attention_layers[li], torch.nn.Identity):
             h = _attention(enc.attention_layers[li], h)
         fmaps.append(h)
+    return fmaps
 
-    act = _ACT.get(dec.activation.__name__)
+
+def _upsampled(blk, h):           # (A) of DecoderBlock: resize-conv (default) or the ConvTranspose2d ablation path
+    if blk.use_resize_conv:
+        return ConvFn.apply(UpsampleFn.apply(h), blk.conv_up.weight, blk.conv_up.bias, None, None, 1, 1)
+    return conv_transpose2x(h, blk.transpose)
+
+
+def decoder_block_forward(blk, cur, skip, t):
+    """DecoderBlock.forward (reference score_unet.py:559-627) for a block WITH norms: NHWC in, NHWC out"""
+    group = blk.norm_kind == "group"
+    G1 = max(1, min(blk.gn_groups, blk.input_channels)) if group else blk.input_channels
+    G2 = max(1, min(blk.gn_groups, blk.output_channels)) if group else blk.output_channels
+    g = lambda n: (n.weight, n.bias) if group else (None, None)   # noqa: E731
+    act = _ACT.get(type(blk.activation).__name__)
+    if act is None:
+        raise NotImplementedError(f"decoder activation {type(blk.activation).__name__} not implemented natively")
+    a = GroupNormFn.apply(_upsampled(blk, cur), *g(blk.norm1), None, None, N.NONE, G1, 1e-5)
+    c2 = ConvFn.apply(a, blk.conv.weight, blk.conv.bias, None, None, 1, 1)
+    tbd = None if t is None else _tproj(t, None, None, blk.sinusoidal_embedding, blk.time_projection_layer)
+    out = GroupNormFn.apply(c2, *g(blk.norm2), skip, tbd, act, G2, 1e-5)
+    if blk.compute_attn:
+        out = _attention(blk.attention, out)
+    return out
+
+
+def decoder_forward(dec, fmaps, t):
+    """Decoder.forward up to (not including) final_layer.conv: the 4 residual blocks and the final block's upsampling convolution"""
     cur = fmaps[4]
     for i, blk in enumerate(dec.residual_layers):
-        group = dec.norm == "group"
-        G1 = max(1, min(dec.gn_groups, blk.input_channels)) if group else blk.input_channels
-        G2 = max(1, min(dec.gn_groups, blk.output_channels)) if group else blk.output_channels
-        g = lambda n: (n.weight, n.bias) if group else (None, None)   # noqa: E731
-        a = upsampled(blk, cur)
-        a = GroupNormFn.apply(a, *g(blk.norm1), None, None, N.NONE, G1, 1e-5)
-        c2 = ConvFn.apply(a, blk.conv.weight, blk.conv.bias, None, None, 1, 1)
-        tbd = tproj(blk.sinusoidal_embedding, blk.time_projection_layer, False)
-        cur = GroupNormFn.apply(c2, *g(blk.norm2), fmaps[3 - i], tbd, act, G2, 1e-5)
-        if blk.compute_attn:
-            cur = _attention(blk.attention, cur)
-    fin = dec.final_layer
-    a = upsampled(fin, cur)
-    if _NBT:
-        with torch.no_grad():
-            torch._foreach_add_(list(_NBT), 1)
-    return Cout1Fn.apply(a, fin.conv.weight, fin.conv.bias, t, sigma)
+        cur = decoder_block_forward(blk, cur, fmaps[3 - i], t)
+    return _upsampled(dec.final_layer, cur)
+
+
+# ---- stand-alone sub-module calls (reference score_unet.py: Encoder.forward :247-364, DecoderBlock.forward :559-627,
+# Decoder.forward :733-758): NCHW tensors at the boundary like the reference, native ops inside ------------------------------------
+def _nhwc(x):
+    B, Cc, H, W = x.shape
+    out = torch.empty(B, H, W, Cc, device=x.device)
+    N.check(_L().sbgm_nchw_to_nhwc(N.f32c(x).data_ptr(), out.data_ptr(), B, H, W, Cc, _st()))
+    return out
+
+
+class _ToNCHW(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        B, H, W, Cc = x.shape
+        out = torch.empty(B, Cc, H, W, device=x.device)
+        N.check(_L().sbgm_nhwc_to_nchw(x.data_ptr(), out.data_ptr(), B, H, W, Cc, _st()))
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _ToNHWC.apply(dy.contiguous())
+
+
+class _ToNHWC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return _nhwc(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _ToNCHW.apply(dy.contiguous())
+
+
+def _standalone(fn):
+    """run `fn` with the per-step scratch pools reset, as forward_train does for the whole network"""
+    def wrapped(dev, *a, **k):
+        _NBT.clear()
+        _zero_reset(dev)
+        _ACTIVE_ARENA[0] = None
+        out = fn(*a, **k)
+        _bump_nbt()
+        return out
+    return wrapped
+
+
+def encoder_call(enc, x, t, y=None, cond_img=None, lsm_cond=None, topo_cond=None):
+    N.require_device(x)
+    for name, c in (("lsm_cond", lsm_cond), ("topo_cond", topo_cond)):
+        if c is not None and c.shape[0] != x.shape[0]:
+            raise ValueError(f"Batch mismatch: x= {x.shape[0]}, {name}={c.shape[0]}.")                  # reference :275,:280
+    f = lambda v: None if v is None else N.f32c(v.to(x.device))   # noqa: E731
+    t = N.f32c(t.to(x.device).view(-1))
+    yl = None if y is None else y.to(x.device).long().contiguous()
+    fm = _standalone(encoder_forward)(x.device, enc, f(x), t, yl, f(cond_img), f(lsm_cond), f(topo_cond))
+    return tuple(_ToNCHW.apply(v) for v in fm)
+
+
+def decoder_block_call(blk, fmap, prev_fmap=None, t=None):
+    N.require_device(fmap)
+    if prev_fmap is not None and torch.is_tensor(prev_fmap):
+        want = (fmap.shape[0], blk.output_channels, fmap.shape[2] * blk.upsample_scale, fmap.shape[3] * blk.upsample_scale)
+        assert tuple(prev_fmap.shape) == want, f"prev_fmap shape {tuple(prev_fmap.shape)} must match output shape {want}"   # reference :596-597
+    else:
+        prev_fmap = None
+    if t is not None and t.dim() > 1 and t.shape[-1] == blk.time_embedding:
+        raise NotImplementedError("DecoderBlock.forward takes the time vector [B]; a precomputed embedding is not supported natively")
+    tt = None if t is None else N.f32c(t.to(fmap.device).view(-1))
+
+    def run():
+        cur, skip = _ToNHWC.apply(N.f32c(fmap)), (None if prev_fmap is None else _ToNHWC.apply(N.f32c(prev_fmap)))
+        if isinstance(blk.norm1, torch.nn.Identity):        # the Decoder's final block: no norms, identity activation (:726-730)
+            a = _upsampled(blk, cur)
+            if blk.output_channels != 1 or skip is not None or tt is not None:
+                raise NotImplementedError("a norm-free DecoderBlock is implemented for the Decoder's final layer (C -> 1, no skip, no time)")
+            return Cout1Fn.apply(a, blk.conv.weight, blk.conv.bias, None, 0.0)              # already NCHW [B,1,H,W]
+        return _ToNCHW.apply(decoder_block_forward(blk, cur, skip, tt))
+    return _standalone(run)(fmap.device)
+
+
+def decoder_call(dec, *fmaps, t=None):
+    assert len(fmaps) == len(dec.residual_layers) + 1
+    N.require_device(*fmaps)
+    tt = None if t is None else N.f32c(t.to(fmaps[0].device).view(-1))
+
+    def run():
+        nh = [_ToNHWC.apply(N.f32c(f)) for f in fmaps]
+        a = decoder_forward(dec, nh, tt)
+        fin = dec.final_layer
+        return Cout1Fn.apply(a, fin.conv.weight, fin.conv.bias, None, 0.0)
+    return _standalone(run)(fmaps[0].device)

@@ -115,8 +115,10 @@ def test_no_cpu_fallback():
     with pytest.raises(N.NativeError):
         with torch.no_grad():
             net(torch.randn(1, 1, 32, 32), torch.rand(1), cond_img=torch.randn(1, 1, 32, 32))
-    with pytest.raises(NotImplementedError):
-        net.encoder(torch.randn(1, 2, 32, 32))
+    with pytest.raises(N.NativeError):                       # stand-alone sub-module calls are native too
+        net.encoder(torch.randn(1, 1, 32, 32), torch.rand(1), cond_img=torch.randn(1, 1, 32, 32))
+    with pytest.raises(NotImplementedError):                 # leaf containers have no forward of their own
+        net.encoder.layer1[0](torch.randn(1, 64, 8, 8))
     with pytest.raises(N.NativeError):
         S.pc_sampler(net, S.marginal_prob_std_fn, S.diffusion_coeff_fn, batch_size=1, num_steps=2, device="cpu", img_size=32,
                      cond_img=torch.randn(1, 1, 32, 32))

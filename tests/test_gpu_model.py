@@ -317,3 +317,41 @@ def test_sixteen_heads_from_the_reference_sweep_space():
     po, pn = dict(ora.named_parameters()), dict(net.named_parameters())
     worst = max(maxrel(pn[k].grad.cpu(), po[k].grad) for k in po if ".attention" in k or ".mha." in k)
     assert worst < 1e-4, worst
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_standalone_submodule_calls_match_the_oracle(mode):
+    """Encoder.forward / Decoder.forward / DecoderBlock.forward called on their own, NCHW in and out like the reference's modules
+    (score_unet.py:247-364, :559-627, :733-758), in eval and train mode; in train mode gradients flow through them"""
+    ora, net, _ = build_pair(5, 4)
+    g = torch.Generator().manual_seed(44)
+    B = 4
+    x, cond = torch.randn(B, 1, 64, 64, generator=g) * 3, torch.randn(B, 1, 64, 64, generator=g)
+    lsm = torch.cat([(torch.rand(B, 1, 64, 64, generator=g) > 0.5).float(), torch.ones(B, 1, 64, 64)], 1)
+    topo = torch.cat([torch.rand(B, 1, 64, 64, generator=g), torch.ones(B, 1, 64, 64)], 1)
+    y, t = torch.randint(0, 5, (B,), generator=g), torch.rand(B, generator=g) * 0.9 + 0.05
+    ora.train(mode == "train"), net.train(mode == "train")
+    ctx = torch.enable_grad() if mode == "train" else torch.no_grad()
+    with ctx:
+        fo = ora.encoder(x, t, y=y, cond_img=cond, lsm_cond=lsm, topo_cond=topo)
+        fn = net.encoder(x.cuda(), t.cuda(), y=y.cuda(), cond_img=cond.cuda(), lsm_cond=lsm.cuda(), topo_cond=topo.cuda())
+        assert len(fn) == 5
+        for a, b in zip(fn, fo):
+            assert a.shape == b.shape and maxrel(a.detach().cpu(), b.detach()) <= TOL
+        do = ora.decoder(*fo, t=t)
+        dn = net.decoder(*fn, t=t.cuda())
+        assert dn.shape == (B, 1, 64, 64) and maxrel(dn.detach().cpu(), do.detach()) <= TOL
+        blk_o, blk_n = ora.decoder.residual_layers[2], net.decoder.residual_layers[2]
+        bo = blk_o(fo[2], fo[1], t)
+        bn = blk_n(fn[2], fn[1], t.cuda())
+        assert maxrel(bn.detach().cpu(), bo.detach()) <= TOL
+        assert maxrel(net.decoder.final_layer(bn.new_zeros(B, 64, 32, 32) + 0.5).cpu(), ora.decoder.final_layer(torch.zeros(B, 64, 32, 32) + 0.5).detach()) <= TOL
+    if mode == "train":
+        do.square().mean().backward()
+        dn.square().mean().backward()
+        po, pn = dict(ora.named_parameters()), dict(net.named_parameters())
+        for k in ("encoder.conv1.weight", "encoder.layer3.0.conv1.weight", "decoder.residual_layers.1.attention.mha.in_proj_weight",
+                  "decoder.final_layer.conv.weight", "encoder.label_emb.weight"):
+            assert maxrel(pn[k].grad.cpu(), po[k].grad) < 1e-3, k
+    with pytest.raises(AssertionError):                      # reference :596-597
+        net.decoder.residual_layers[2](fn[2].detach(), fn[2].detach(), t.cuda())

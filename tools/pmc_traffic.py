@@ -2,7 +2,7 @@
 """HBM-side traffic per kernel instantiation from two rocprofv3 PMC passes of bench.py (FETCH_SIZE and WRITE_SIZE are
 collected in separate passes: together they do not fit the TCC counter slots).
 
-    python tools/pmc_traffic.py fetch_counter_collection.csv write_counter_collection.csv [out.json]
+    python tools/pmc_traffic.py fetch_counter_collection.csv write_counter_collection.csv [out.json [workload]]
 
 Only the dispatches of the last complete SDE step (between the last two em_update launches) are used, i.e. the tuned
 steady-state kernels, not the autotuner's candidates.  gfx950 correction (MI355X_MICROARCH.md, HBM section):
@@ -56,6 +56,12 @@ def main():
     out["bytes_per_step"] = tot
     print(f"total per SDE step: {tot / 1e6:.1f} MB")
     if len(sys.argv) > 3:
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        out["source_hash"] = bench.kernel_source_hash()          # bench.py refuses this file once the kernel sources change
+        if len(sys.argv) > 4:
+            out["workload"] = sys.argv[4]
         json.dump(out, open(sys.argv[3], "w"), indent=1)
 
 
