@@ -88,14 +88,41 @@ def build_model(dev, n_cond=1):
     return net
 
 
+def usable_cores():
+    """Every core this process can actually run on: the affinity mask, capped by the cgroup CPU quota when there is one (a GPU box
+    shows all 256 logical CPUs of the host in the mask but schedules a one-GPU job on a 16-core share: 256 threads on that share
+    ran the oracle 100x slower than 16).  Returns (threads, how they were counted)."""
+    n = os.cpu_count() or 1
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+    how = f"affinity mask {n}"
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:                      # cgroup v2: "<quota|max> <period>"
+            q, per = f.read().split()[:2]
+            if q != "max":
+                quota = float(q) / float(per)
+    except Exception:
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f, open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as g:
+                q, per = float(f.read()), float(g.read())
+                if q > 0:
+                    quota = q / per
+        except Exception:
+            pass
+    if quota is not None and quota < n:
+        import math
+        n = max(1, int(math.ceil(quota)))
+        how += f", cgroup CPU quota {quota:.1f} -> {n}"
+    return n, how
+
+
 def cpu_baseline(batch, hw, budget_s=20.0):
     """Oracle on the host cores: 1 warm-up + as many Euler-Maruyama steps as fit the budget (at least 2)."""
     from oracle import torch_ref as O
-    cores = os.cpu_count() or 1
-    try:
-        cores = len(os.sched_getaffinity(0))       # every core this process may run on (SURVEY 8d: all cores, N stated)
-    except Exception:
-        pass
+    cores, how = usable_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(42)
     ora = O.build_scorenet(1).eval()
@@ -119,7 +146,7 @@ def cpu_baseline(batch, hw, budget_s=20.0):
         pass
     return {"value": batch * n / dt, "unit": "denoising steps/s", "cores": cores, "kind": "port",
             "sample": f"{n} Euler-Maruyama steps of the CPU oracle at batch {batch}, {hw}x{hw}, after 1 warm-up "
-                      f"({dt:.1f} s, PyTorch-CPU {torch.__version__}, {model})"}
+                      f"({dt:.1f} s, PyTorch-CPU {torch.__version__}, {model}; threads = {how})"}
 
 
 def train_secondary(dev, steps=10, warmup=3):
