@@ -552,8 +552,6 @@ def main():
                 "whole_eval": {"ms": ms_eval, "gflop": flops_eval * 1e-9,
                                "fp32_frac": flops_eval / (ms_eval * 1e-3) / (PEAK_FP32_TFLOPS * 1e12),
                                "hbm_frac_layer_fused_bytes": BYTES_PER_EVAL(B, HW) / (ms_eval * 1e-3) / (PEAK_HBM_GBS * 1e9)}}
-        if not a.no_cpu_baseline and world == 1:                   # the CPU reference leg is reported at N=1 only
-            cpu = cpu_baseline(B, HW)
     secondary = None
     if rank == 0 and world == 1 and not a.no_secondary and B == 32 and HW == 128:
         # BASELINE configs[2] beside the headline, so the training step is driver-timed too: per-GPU shape (batch 8, C_in = 5)
@@ -563,6 +561,8 @@ def main():
             secondary = {"train_c3": train_secondary(dev)}
         except Exception as e:                                     # never lose the headline line to the secondary measurement
             secondary = {"train_c3": {"error": f"{type(e).__name__}: {e}"}}
+    if rank == 0 and not a.no_cpu_baseline and world == 1:         # the CPU reference leg is reported at N=1 only; it runs LAST: its
+        cpu = cpu_baseline(B, HW)                                  # OpenMP workers keep spinning on the host cores the GPU legs launch from
 
     if rank == 0:
         value = B * a.steps * world / dt
