@@ -274,6 +274,11 @@ int sbgm_act_inplace(float* x, int64_t n, int act, void* stream);
  * (stride-2 layers with in_dil = 2 and an explicit output size).
  * ---------------------------------------------------------------------------------------------------------- */
 int sbgm_conv_pack_weight_dgrad(const float* w_oihw, float* packed, int Cout, int Cin, int KH, int KW, void* stream);
+/* Data gradient of an 8x8 / stride-2 / pad-3 convolution (the encoder's conv2, score_unet.py:214-219) by output phase instead of
+ * through a zero-inserted dy: builds the OIHW operator [4*Cin][Cout][5][5] whose 5x5 / stride-1 / pad-2 convolution over dy
+ * [B,OH,OW,Cout] yields the 4 phases (py, px, ci) of dx; sbgm_depth_to_space2 interleaves them into dx [B,2*OH,2*OW,Cin].
+ * 2.56x fewer MACs than the dilated form.  Pack the result with sbgm_conv_pack_weight(.., 4*Cin, Cout, 5, 5, Cout). */
+int sbgm_conv8x8s2_dgrad_phase_weight(const float* w_oihw, float* out_oihw, int Cout, int Cin, void* stream);
 /* dW (OIHW) = sum_p dy[p,:] (x) x[p@tap,:]; ws: >= KH*KW*Cout*c_pad floats.  For a 1x1 kernel with c_pad == Cin (and c_pad % 64
  * == 0) ws may be dw_oihw itself: the partial sums then meet directly in the gradient and the layout pass is skipped. */
 int sbgm_conv2d_wgrad(const float* dy, const float* x, float* dw_oihw, float* ws, int B, int H, int W, int c_pad, int Cin,

@@ -123,6 +123,7 @@ SIGNATURES = {
     "sbgm_conv3x3_cout1_fwd": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _i, _i, _i, _i, _vp]),
     "sbgm_act_inplace": (_i, [_vp, _i64, _i, _vp]),
     "sbgm_conv_pack_weight_dgrad": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "sbgm_conv8x8s2_dgrad_phase_weight": (_i, [_vp, _vp, _i, _i, _vp]),
     "sbgm_conv2d_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "sbgm_conv2d_wgrad_bias": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp]),
     "sbgm_colsum": (_i, [_vp, _vp, _vp, _i, _i, _vp]),

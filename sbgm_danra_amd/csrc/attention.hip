@@ -257,9 +257,10 @@ int sbgm_launch_mha_core(const float* qkv, float* out, int B, int S, int C, int 
     const float scale = 1.0f / sqrtf((float)d);
     static const bool lds_ok = getenv("SBGM_NO_LDS_ATTENTION") == nullptr;
     if (lds_ok && S >= 128 && d16 <= 4) {
-        // query blocks of one (sample, head) are dealt to `qsplit` workgroups: enough of them for ~2 per CU, at most 16 blocks each
+        // query blocks of one (sample, head) are dealt to `qsplit` workgroups: one workgroup per CU if possible (every split stages
+        // K / V again, so fewer is better for traffic), at most 16 blocks each
         const int qblocks = (S + 15) / 16, bh = B * heads;
-        int qsplit = std::max((512 + bh - 1) / bh, (qblocks + 4 * MHA_NQ - 1) / (4 * MHA_NQ));
+        int qsplit = std::max((256 + bh - 1) / bh, (qblocks + 4 * MHA_NQ - 1) / (4 * MHA_NQ));
         qsplit = std::max(1, std::min(qsplit, qblocks));
         const size_t lds = (size_t)MHA_KCH * (d16 | 1) * 64 + (size_t)MHA_KCH * (16 * d16 + 4) * 4;
         const dim3 grid(bh * qsplit), block(256);

@@ -93,6 +93,9 @@ int sbgm_batchnorm_bwd_apply(const float* x, const float* dy, const float* y, co
     return sbgm_launch_batchnorm_bwd_apply(x, dy, y, gamma, tbias_after, mean_rstd, relu, dx, dres, dgamma, dbeta, ws, sync_sums, n_total,
                                            B, HW, C, ST);
 }
+int sbgm_conv8x8s2_dgrad_phase_weight(const float* w_oihw, float* out_oihw, int Cout, int Cin, void* stream) {
+    return sbgm_launch_dgrad_phase_weight(w_oihw, out_oihw, Cout, Cin, ST);
+}
 int sbgm_groupnorm_stats(const float* x, void* stats_ws, int B, int HW, int C, int G, int* chunks, void* stream) {
     SBGM_CHECK(chunks != nullptr, "groupnorm_stats: chunks is required");
     return sbgm_launch_gn_partial(x, static_cast<double*>(stats_ws), B, HW, C, G, chunks, ST);

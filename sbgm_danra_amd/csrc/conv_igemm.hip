@@ -453,7 +453,8 @@ int sbgm_launch_conv(const ConvGeom& g, ConvParams p, const ConvTile& cfg, float
         rc = launch_geom<KH_, KW_, S_, PAD_, CM_>(p, cfg, grid, st);
     SBGM_GEOM(8, 8, 2, 3, 0) SBGM_GEOM(8, 8, 2, 3, 4) SBGM_GEOM(8, 8, 2, 3, 8) SBGM_GEOM(8, 8, 2, 3, 2)
     SBGM_GEOM(3, 3, 1, 1, 0) SBGM_GEOM(3, 3, 2, 1, 0) SBGM_GEOM(1, 1, 2, 0, 0) SBGM_GEOM(1, 1, 1, 0, 0)
-    SBGM_GEOM(8, 8, 1, 4, 0)                       // data-gradient of the 8x8/s2/p3 stem convolution
+    SBGM_GEOM(8, 8, 1, 4, 0)                       // data-gradient of the 8x8/s2/p3 stem convolution (zero-dilated form)
+    SBGM_GEOM(5, 5, 1, 2, 0)                       // ... and its phase-decomposed form (backward.hip: dgrad_phase_weight_kernel)
 #undef SBGM_GEOM
     SBGM_CHECK(rc == 0, "conv: no kernel for k=%dx%d s=%d p=%d cs=%d tile=%dx%d ws=%d", g.kh, g.kw, g.stride, g.pad, p.Cs,
                cfg.fco, cfg.fpx, cfg.ws);

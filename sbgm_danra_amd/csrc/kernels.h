@@ -221,6 +221,8 @@ int sbgm_launch_sample_extremes(const float* x, int B, size_t per, float q, floa
 int sbgm_launch_conv_wgrad(const float* dy, const float* x, float* dw_oihw, float* dwp_ws, int B, int H, int W, int Cs, int Cin,
                            int Cout, int KH, int KW, int S, int PAD, hipStream_t st,
                            float* dbias = nullptr);   // optional bias gradient [Cout] (zeroed by the launcher unless pre-zeroed)
+// OIHW operator [4*Cin][Cout][5][5] of the phase-decomposed data gradient of an 8x8/s2/p3 convolution (see backward.hip)
+int sbgm_launch_dgrad_phase_weight(const float* w_oihw, float* out, int Cout, int Cin, hipStream_t st);
 int sbgm_launch_colsum(const float* x, const float* y, float* out, int M, int C, hipStream_t st);
 int sbgm_launch_samplesum(const float* x, float* out, int B, int HW, int C, hipStream_t st);
 int sbgm_launch_groupnorm_bwd(const float* x, const float* dy, const float* gamma, const float* beta, const float* skip,

@@ -310,7 +310,19 @@ class ConvFn(torch.autograd.Function):
         B, H, W, cs = x.shape
         cout, cin, k, _ = w.shape
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and k == 8 and stride == 2 and pad == 3 and cs == cin and cin % 16 == 0 and cout % 16 == 0 \
+                and H % 2 == 0 and W % 2 == 0:
+            # stem conv2: phase-decomposed data gradient (5x5 / stride 1 over dy to 4*Cin phase-major channels + depth->space)
+            # instead of an 8x8 convolution over the zero-inserted dy (75 % of whose MACs multiply zeros)
+            wph = torch.empty(4 * cin, cout, 5, 5, device=x.device)
+            N.check(_L().sbgm_conv8x8s2_dgrad_phase_weight(w.data_ptr(), wph.data_ptr(), cout, cin, _st()))
+            pk = torch.empty(_L().sbgm_conv_packed_numel(4 * cin, 5, 5, cout), device=x.device)
+            N.check(_L().sbgm_conv_pack_weight(wph.data_ptr(), pk.data_ptr(), 4 * cin, cout, 5, 5, cout, _st()))
+            ph = torch.empty(B, H // 2, W // 2, 4 * cin, device=x.device)
+            _conv_launch(dy, pk, ph, cout, 4 * cin, 5, 1, 2)
+            dx = torch.empty_like(x)
+            N.check(_L().sbgm_depth_to_space2(ph.data_ptr(), dx.data_ptr(), B, H // 2, W // 2, cin, _st()))
+        elif ctx.needs_input_grad[0]:
             if cs != cin or cs % 32:
                 raise NotImplementedError("data gradient w.r.t. a channel-padded input is not needed on this path")
             packed = ctx.packed_bwd

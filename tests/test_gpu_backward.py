@@ -288,3 +288,22 @@ def test_two_sgd_steps_track_the_oracle():
         want = ora(x, t, y, cond, lsm, topo)
         got = net(x.cuda(), t.cuda(), y.cuda(), cond.cuda(), lsm.cuda(), topo.cuda()).cpu()
     assert maxrel(got, want) < 1e-3         # the two models' weights now differ by up to ~5e-4 (above)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H", [(2, 64, 64, 32), (8, 64, 64, 64), (1, 32, 48, 16), (3, 64, 128, 24)])
+def test_stem_conv_phase_decomposed_data_gradient(B, Cin, Cout, H):
+    """8x8 / stride 2 / pad 3 (encoder.conv2): dx through the 5x5 phase operator + depth->space instead of the zero-dilated 8x8"""
+    x, w = rnd(B, Cin, H, H), rnd(Cout, Cin, 8, 8, seed=1, scale=1 / math.sqrt(Cin * 64))
+    go = rnd(B, Cout, H // 2, H // 2, seed=5)
+    xr, wr = leaf(x), leaf(w)
+    F.conv2d(xr, wr, None, 2, 3).backward(go)
+    xd, wd = leaf(nhwc(x), True), leaf(w, True)
+    T.ConvFn.apply(xd, wd, None, None, None, 2, 3).backward(nhwc(go).cuda())
+    assert maxrel(nchw(xd.grad.cpu()), xr.grad) < GT and maxrel(wd.grad.cpu(), wr.grad) < GT
+    # the operator itself: only the taps of the right parity survive
+    lib = N.lib()
+    ph = torch.empty(4 * Cin, Cout, 5, 5, device="cuda")
+    N.check(lib.sbgm_conv8x8s2_dgrad_phase_weight(wd.data_ptr(), ph.data_ptr(), Cout, Cin, N.stream()))
+    ph = ph.cpu().view(2, 2, Cin, Cout, 5, 5)
+    assert torch.equal(ph[0, 0, :, :, 0, 0], w[:, :, 7, 7].t()) and torch.equal(ph[1, 1, :, :, 4, 4], w[:, :, 0, 0].t())
+    assert float(ph[0, :, :, :, 4, :].abs().max()) == 0.0 and float(ph[1, :, :, :, 0, :].abs().max()) == 0.0
