@@ -290,7 +290,7 @@ def test_two_sgd_steps_track_the_oracle():
     assert maxrel(got, want) < 1e-3         # the two models' weights now differ by up to ~5e-4 (above)
 
 
-@pytest.mark.parametrize("B,Cin,Cout,H", [(2, 64, 64, 32), (8, 64, 64, 64), (1, 32, 48, 16), (3, 64, 128, 24)])
+@pytest.mark.parametrize("B,Cin,Cout,H", [(2, 64, 64, 32), (8, 64, 64, 64), (1, 32, 64, 16), (3, 64, 128, 24)])
 def test_stem_conv_phase_decomposed_data_gradient(B, Cin, Cout, H):
     """8x8 / stride 2 / pad 3 (encoder.conv2): dx through the 5x5 phase operator + depth->space instead of the zero-dilated 8x8"""
     x, w = rnd(B, Cin, H, H), rnd(Cout, Cin, 8, 8, seed=1, scale=1 / math.sqrt(Cin * 64))
