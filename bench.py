@@ -401,15 +401,13 @@ def main():
     if a.mode == "domain":
         return domain_bench(a)
 
-    rank, world = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
-    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
     if world != a.gpus:
         sys.exit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {a.gpus}, or without a "
                  f"torchrun environment (bench.py then starts the ranks itself)")
     import torch.distributed as dist
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+    from sbgm_danra_amd import parallel
+    rank, world, local = parallel.init_distributed()       # RCCL ("nccl") over xGMI: only the barrier and the max-over-ranks of the time
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

@@ -21,12 +21,16 @@ import torch.distributed as dist
 
 def init_distributed(backend: str | None = None) -> tuple[int, int, int]:
     """Join the process group described by RANK/WORLD_SIZE/LOCAL_RANK/MASTER_* (torchrun contract).
-    Returns (rank, world, local_rank); world == 1 without those variables (no group is created)."""
+    Returns (rank, world, local device index); world == 1 without those variables (no group is created).
+    The backend is RCCL ("nccl") on GPUs; SBGM_DIST_BACKEND=gloo overrides it — that is how the multi-rank code paths are rehearsed
+    on a one-GPU box, where all ranks share device 0 (local index = LOCAL_RANK modulo the visible device count)."""
     world = int(os.environ.get("WORLD_SIZE", 1))
     rank, local = int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0))
+    if torch.cuda.is_available():
+        local %= max(1, torch.cuda.device_count())
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        backend = backend or os.environ.get("SBGM_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
             dist.init_process_group(backend, device_id=torch.device("cuda", local))

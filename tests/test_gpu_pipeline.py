@@ -299,3 +299,29 @@ def test_graph_steps_with_two_batch_shapes_use_their_own_gradients(cfg_path):
         worst = max(float((got[k] - want[k]).abs().max() / want[k].abs().max().clamp_min(1e-30)) for k in want)
         assert worst < 1e-4, (i, worst)
     assert len(pipe._graphs) == 2
+
+
+@pytest.mark.parametrize("mode,extra", [("sample", ["--batch", "2", "--size", "64"]), ("train", ["--batch", "2", "--size", "64"]),
+                                        ("train", ["--batch", "2", "--size", "64", "--sync-bn"]), ("domain", [])])
+def test_bench_multi_rank_rehearsal_on_one_gpu(mode, extra):
+    """`python bench.py --gpus 2` as the driver calls it (no torchrun environment): bench.py starts the 2 rank processes itself; here
+    they share this box's one GPU and talk over gloo (SBGM_DIST_BACKEND) — every multi-rank code path except RCCL itself: rank
+    spawn, process group, per-rank seeds, barrier + max-over-ranks timing, gradient all-reduce on the arena, SyncBatchNorm,
+    tile sharding + merge, rank-0-only JSON line"""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["SBGM_DIST_BACKEND"] = "gloo"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "2", "--mode", mode, "--no-cpu-baseline",
+           "--no-autotune", "--no-secondary"] + extra
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["value"] > 0 and np.isfinite(out["value"])
+    if mode == "sample":
+        assert out["config"]["global_batch"] == 4 and out["scaling"] == "weak"
+    if mode == "train":
+        assert np.isfinite(out["config"]["final_loss"]) and ("SyncBatchNorm" in out["config"]["workload"]) == ("--sync-bn" in extra)
