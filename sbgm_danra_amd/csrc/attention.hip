@@ -75,11 +75,11 @@ __global__ __launch_bounds__(256) void mha_core_kernel(const float* __restrict__
         mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
         mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
         const float m_new = fmaxf(m_run, mx);            // finite: every block has at least one valid key
-        const float alpha = expf(m_run - m_new);         // first block: exp(-inf) = 0
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);   // first block: 2^(-inf) = 0
         float ps = 0.f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            st[e] = expf(st[e] - m_new);                 // masked keys: exp(-inf) = 0
+            st[e] = __builtin_amdgcn_exp2f(st[e] - m_new);   // masked keys: 2^(-inf) = 0
             ps += st[e];
         }
         ps += __shfl_xor(ps, 16, 64);
@@ -112,13 +112,13 @@ __global__ __launch_bounds__(256) void mha_core_kernel(const float* __restrict__
         float m_all = m_run;
 #pragma unroll
         for (int ww = 1; ww < 4; ++ww) m_all = fmaxf(m_all, ml[(ww * 64 + lane) * 2]);
-        float f0 = expf(m_run - m_all);
+        float f0 = __builtin_amdgcn_exp2f(m_run - m_all);
         l_run *= f0;
 #pragma unroll
         for (int j = 0; j < D16; ++j) o[j] *= f0;
 #pragma unroll
         for (int ww = 1; ww < 4; ++ww) {
-            const float fw = expf(ml[(ww * 64 + lane) * 2] - m_all);          // exp(-inf) = 0 for idle waves
+            const float fw = __builtin_amdgcn_exp2f(ml[(ww * 64 + lane) * 2] - m_all);   // 2^(-inf) = 0 for idle waves
             l_run += ml[(ww * 64 + lane) * 2 + 1] * fw;
 #pragma unroll
             for (int j = 0; j < D16; ++j) o[j] += ol[(ww * D16 + j) * 64 + lane] * fw;
@@ -142,8 +142,8 @@ __global__ __launch_bounds__(256) void mha_core_kernel(const float* __restrict__
 //            conflict-free ds_read_b128;
 //   V chunk  [key][d + 4]: the A operand of O^T = V^T P^T needs 4 keys x 1 dim per lane = 4 ds_read_b32, conflict-free with the
 //            row stride = 4 (mod 8) floats (LDS time stays ~5 % of the MFMA time).
-constexpr int MHA_KCH = 128, MHA_NQ = 4;
-template <int D16>
+constexpr int MHA_KCH = 128, MHA_NQ_MAX = 4;
+template <int D16, int MHA_NQ>        // MHA_NQ query blocks per wave, processed together (no branches between their chains)
 __global__ __launch_bounds__(256) void mha_core_lds_kernel(const float* __restrict__ qkv, float* __restrict__ out, int B, int S, int C,
                                                            int heads, float scale, int qsplit) {
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -158,7 +158,6 @@ __global__ __launch_bounds__(256) void mha_core_lds_kernel(const float* __restri
     const int qs = w % qsplit; w /= qsplit;
     const int h = w % heads;
     const int b = w / heads;
-    const int qblocks = (S + 15) >> 4;
     const size_t row_stride = 3 * (size_t)C;
     const float* base = qkv + (size_t)b * S * row_stride + (size_t)h * d;
 
@@ -191,17 +190,24 @@ __global__ __launch_bounds__(256) void mha_core_lds_kernel(const float* __restri
         }
         __syncthreads();
         const int kend = min(MHA_KCH, S - c0);
+        // key blocks outermost, this wave's query blocks innermost: one K / V fragment read serves all of them and their
+        // QK^T -> softmax -> PV chains are independent, so the latencies of one hide behind the MFMAs of the others
+        for (int kl = 0; kl < kend; kl += 16) {
+            f32x4 kf[D16];
 #pragma unroll
-        for (int n = 0; n < MHA_NQ; ++n) {
-            if ((qs + qsplit * (wave + 4 * n)) >= qblocks) break;           // wave-uniform
-            for (int kl = 0; kl < kend; kl += 16) {
+            for (int j = 0; j < D16; ++j) kf[j] = Kl[((kl + r16) * KU + j) * 4 + ((kq + ((kl + r16) >> 1)) & 3)];
+            float vv[D16][4];
+#pragma unroll
+            for (int j = 0; j < D16; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) vv[j][e] = Vl[(kl + 4 * kq + e) * VS + 16 * j + r16];
+#pragma unroll
+            for (int n = 0; n < MHA_NQ; ++n) {                 // a slot beyond the last query block computes on zero queries (stores are masked)
                 f32x4 st = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                for (int j = 0; j < D16; ++j) {
-                    const f32x4 kf = Kl[((kl + r16) * KU + j) * 4 + ((kq + ((kl + r16) >> 1)) & 3)];
+                for (int j = 0; j < D16; ++j)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) st = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[e], qf[n][j][e], st, 0, 0, 0);
-                }
+                    for (int e = 0; e < 4; ++e) st = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[j][e], qf[n][j][e], st, 0, 0, 0);
                 float mx = -INFINITY;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
@@ -211,11 +217,11 @@ __global__ __launch_bounds__(256) void mha_core_lds_kernel(const float* __restri
                 mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
                 mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
                 const float m_new = fmaxf(m_run[n], mx);
-                const float alpha = expf(m_run[n] - m_new);
+                const float alpha = __builtin_amdgcn_exp2f(m_run[n] - m_new);
                 float ps = 0.f;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    st[e] = expf(st[e] - m_new);
+                    st[e] = __builtin_amdgcn_exp2f(st[e] - m_new);
                     ps += st[e];
                 }
                 ps += __shfl_xor(ps, 16, 64);
@@ -226,10 +232,7 @@ __global__ __launch_bounds__(256) void mha_core_lds_kernel(const float* __restri
                 for (int j = 0; j < D16; ++j) {
                     o[n][j] *= alpha;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float vv = Vl[(kl + 4 * kq + e) * VS + 16 * j + r16];
-                        o[n][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv, st[e], o[n][j], 0, 0, 0);
-                    }
+                    for (int e = 0; e < 4; ++e) o[n][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(vv[j][e], st[e], o[n][j], 0, 0, 0);
                 }
             }
         }
@@ -254,22 +257,30 @@ int sbgm_launch_mha_core(const float* qkv, float* out, int B, int S, int C, int 
     const int d = C / heads;
     SBGM_CHECK(d % 4 == 0 && d <= 512, "mha: head dim %d must be a multiple of 4 (<= 512)", d);
     const int d16 = (d + 15) / 16;
-    const float scale = 1.0f / sqrtf((float)d);
+    // scores are kept in base-2 units (q pre-scaled by log2(e)/sqrt(d)): softmax = 2^(s - max) / sum, evaluated with the hardware
+    // exp2 (1 ulp) — the full-range expf expansion cost as many VALU cycles per key block as its MFMAs
+    const float scale = 1.4426950408889634f / sqrtf((float)d);
     static const bool lds_ok = getenv("SBGM_NO_LDS_ATTENTION") == nullptr;
     if (lds_ok && S >= 128 && d16 <= 4) {
         // query blocks of one (sample, head) are dealt to `qsplit` workgroups: one workgroup per CU if possible (every split stages
         // K / V again, so fewer is better for traffic), at most 16 blocks each
         const int qblocks = (S + 15) / 16, bh = B * heads;
-        int qsplit = std::max((256 + bh - 1) / bh, (qblocks + 4 * MHA_NQ - 1) / (4 * MHA_NQ));
+        int qsplit = std::max((256 + bh - 1) / bh, (qblocks + 4 * MHA_NQ_MAX - 1) / (4 * MHA_NQ_MAX));
         qsplit = std::max(1, std::min(qsplit, qblocks));
+        const int per_wave = (qblocks + 4 * qsplit - 1) / (4 * qsplit);          // query blocks per wave
+        const int nq = per_wave <= 1 ? 1 : per_wave <= 2 ? 2 : 4;
         const size_t lds = (size_t)MHA_KCH * (d16 | 1) * 64 + (size_t)MHA_KCH * (16 * d16 + 4) * 4;
         const dim3 grid(bh * qsplit), block(256);
-        switch (d16) {
-            case 1: hipLaunchKernelGGL((mha_core_lds_kernel<1>), grid, block, lds, st, qkv, out, B, S, C, heads, scale, qsplit); break;
-            case 2: hipLaunchKernelGGL((mha_core_lds_kernel<2>), grid, block, lds, st, qkv, out, B, S, C, heads, scale, qsplit); break;
-            case 3: hipLaunchKernelGGL((mha_core_lds_kernel<3>), grid, block, lds, st, qkv, out, B, S, C, heads, scale, qsplit); break;
-            default: hipLaunchKernelGGL((mha_core_lds_kernel<4>), grid, block, lds, st, qkv, out, B, S, C, heads, scale, qsplit); break;
-        }
+        int rc = 1;
+#define SBGM_MHAL(DD, NN)                                                                                                              \
+    if (d16 == DD && nq == NN) {                                                                                                       \
+        hipLaunchKernelGGL((mha_core_lds_kernel<DD, NN>), grid, block, lds, st, qkv, out, B, S, C, heads, scale, qsplit);            \
+        rc = 0;                                                                                                                        \
+    }
+        SBGM_MHAL(1, 1) SBGM_MHAL(1, 2) SBGM_MHAL(1, 4) SBGM_MHAL(2, 1) SBGM_MHAL(2, 2) SBGM_MHAL(2, 4)
+        SBGM_MHAL(3, 1) SBGM_MHAL(3, 2) SBGM_MHAL(3, 4) SBGM_MHAL(4, 1) SBGM_MHAL(4, 2) SBGM_MHAL(4, 4)
+#undef SBGM_MHAL
+        SBGM_CHECK(rc == 0, "mha: no LDS kernel for head dim %d", d);
         SBGM_LAUNCH_CHECK();
         return 0;
     }
