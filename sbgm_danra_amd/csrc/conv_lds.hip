@@ -19,12 +19,12 @@
 //   IN = 2  bilinear x2 on load (nn.Upsample, align_corners=False): x is the LOW-resolution map [B][H/2][W/2][Cs].  Per stage
 //           the (TH/2+2) x 10 low-res pixels under the patch are loaded (edge-clamped), optionally transformed
 //           act(x*scale + shift + skip) (the pending GroupNorm + skip + time bias + activation of the previous block) and parked
-//           in a small LDS region.  The interpolation is separable: the staging step blends ROWS only (0.25 / 0.75 taps) into a
-//           patch of (TH+2) high-res rows x 10 LOW-res columns, and the column taps are folded into the Winograd input transform
-//           of the sweep: the 4 columns d0..d3 a pair needs are combinations of just 3 low-res neighbours,
+//           in a small LDS region.  A second staging step turns them into the Winograd-transformed input V = B^T d directly: rows are
+//           blended with the 0.25 / 0.75 taps and the column taps are folded into B^T — the 4 columns d0..d3 an output pair needs
+//           are combinations of just 3 low-res neighbours,
 //             d0 = .75 a + .25 b   d1 = .25 a + .75 b   d2 = .75 b + .25 c   d3 = .25 b + .75 c     (a, b, c = x[m-1], x[m], x[m+1])
-//           so a B fragment costs 3 LDS reads instead of 4 and the 18-wide patch is never built.  The upsampled tensor (134 MB
-//           at the final block of a B=32, 128x128 evaluation) is never written or re-read.
+//           so the 18-wide upsampled patch is never built and the sweep reads ready-made B fragments.  The upsampled tensor
+//           (134 MB at the final block of a B=32, 128x128 evaluation) is never written or re-read.
 #include "common.h"
 #include "kernels.h"
 #include "conv_common.h"
@@ -53,7 +53,7 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(const ConvParams p) {
     constexpr int WQ = NTAP * NCO * 4;          // weight quads (16 B) per stage
     constexpr int PWS = WINO ? PWID + 1 : PWID; // patch row stride in LDS (odd for the Winograd column pairs)
     constexpr int PQ = PH * PWID * 4;           // patch quads loaded per stage
-    constexpr int STAGE_QUADS = WQ + PH * PWS * 4;
+    constexpr int STAGE_QUADS = WQ + (IN == 2 ? PH * 32 : PH * PWS) * 4;   // IN == 2: V patch [PH][4 xi][8 pairs][4 quads]
     constexpr int LH = TH / 2 + 2, LW = TW / 2 + 2;             // IN == 2: low-resolution pixels under the patch
     constexpr int LQ = LH * LW * 4;
     f32x4* wl = reinterpret_cast<f32x4*>(smem_raw);            // [tap][co][4 quads]
@@ -175,33 +175,42 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(const ConvParams p) {
             if (q < LQ) ld[q] = v;
         }
     };
-    constexpr int PQ2 = PH * LW * 4;                           // IN == 2: patch quads = high-res rows x low-res columns
+    // IN == 2: the staged "patch" holds the Winograd-transformed input V itself, [row][xi][pair][quad]: every (row, pair) is
+    // transformed ONCE here instead of once per kh in the sweep, whose B fragments become 4 plain ds_read_b128 with no arithmetic.
+    // Quad rotation (quad + 2*(row & 1)) & 3 with `pair` the fastest index: the 16 lanes of a ds_read_b128 group (4 consecutive
+    // pairs x 2 quads x 2 row parities) hit 16 distinct slots.
+    constexpr int PQ2 = PH * 8 * 4;                            // (row, pair, quad) items per stage
     constexpr int PPT2 = (PQ2 + 255) / 256;
-    auto expand = [&](int lbuf, int buf) {                     // IN == 2: L region -> row-interpolated patch [PH][LW]
+    auto expand = [&](int lbuf, int buf) {
         static_assert(IN != 2 || WINO, "upsample-on-load is built on the Winograd sweep");
         const f32x4* ls = lr0 + lbuf * LQ;
         f32x4* pd = pt0 + buf * STAGE_QUADS;
 #pragma unroll
         for (int u = 0; u < PPT2; ++u) {
             const int q = tid + 256 * u;
-            const int quad = q & 3, pix = q >> 2;
-            const int py = pix / LW, c = pix - py * LW;
+            const int quad = q & 3, pair = (q >> 2) & 7, py = q >> 5;
             const int iy = y0 - 1 + py;
             // output row iy blends L rows a = py >> 1 and a + 1 (y0 is even); weights as PyTorch: even row 0.25 / 0.75 (row 0: 0 / 1),
             // odd row 0.75 / 0.25; rows outside the image are the convolution's zero padding
             const int ra = py >> 1;
             const float wya = (py & 1) ? (iy == 0 ? 0.f : 0.25f) : 0.75f, wyb = 1.f - wya;
             if (q < PQ2) {
-                const f32x4 va = ls[(ra * LW + c) * 4 + quad], vb = ls[((ra + 1) * LW + c) * 4 + quad];
-                const f32x4 o = wya * va + wyb * vb;
-                pd[(py * LW + c) * 4 + ((quad + 2 * (py & 1)) & 3)] = (unsigned)iy < (unsigned)p.H ? o : f32x4{0.f, 0.f, 0.f, 0.f};
+                const f32x4* la = ls + (ra * LW + pair) * 4 + quad;      // low-res neighbours a, b, c of this output pair (columns pair .. pair+2)
+                const f32x4* lb = la + LW * 4;
+                f32x4 xa = wya * la[0] + wyb * lb[0], xb = wya * la[4] + wyb * lb[4], xc = wya * la[8] + wyb * lb[8];
+                if ((unsigned)iy >= (unsigned)p.H) xa = xb = xc = f32x4{0.f, 0.f, 0.f, 0.f};
+                // d0..d3 (header comment) substituted into V = B^T d; at the image's left / right edge d0 / d3 is the convolution's zero
+                // padding, which only changes the coefficients of v0 / v3
+                const bool zl = x0 == 0 && pair == 0, zr = x0 + TW == p.W && pair == 7;
+                const float a0 = zl ? 0.f : 0.75f, b0 = zl ? -0.75f : -0.5f, b3 = zr ? 0.75f : 0.5f, c3 = zr ? 0.f : -0.75f;
+                f32x4* o = pd + ((py * 4) * 8 + pair) * 4 + ((quad + 2 * (py & 1)) & 3);
+                o[0] = a0 * xa + b0 * xb - 0.25f * xc;
+                o[32] = 0.25f * (xa + xc) + 1.5f * xb;
+                o[64] = 0.25f * (xc - xa);
+                o[96] = 0.25f * xa + b3 * xb + c3 * xc;
             }
         }
     };
-    const bool up_zero_left = IN == 2 && x0 == 0 && (r16 & 7) == 0;
-    const bool up_zero_right = IN == 2 && x0 + TW == p.W && (r16 & 7) == 7;
-    const float up_a0 = up_zero_left ? 0.f : 0.75f, up_b0 = up_zero_left ? -0.75f : -0.5f;      // v0 = d0 - d2
-    const float up_b3 = up_zero_right ? 0.75f : 0.5f, up_c3 = up_zero_right ? 0.f : -0.75f;     // v3 = d1 - d3
     stage_load(0);
     stage_store_w(0);
     if (IN != 2) {
@@ -263,17 +272,8 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(const ConvParams p) {
                                     d3 = src[swz(pcol + 3, kq)];
                         v[0][j] = d0 - d2; v[1][j] = d1 + d2; v[2][j] = d2 - d1; v[3][j] = d1 - d3;
                     } else {
-                        // low-res neighbours a, b, c of output pair (r16 & 7); quad rotation (kq + 2*(row & 1)) & 3: the 16 lanes of a
-                        // ds_read_b128 group hit 16 distinct slots (4 consecutive columns x {2 quads} x {2 row parities}).
-                        // d0..d3 (header comment) substituted into V = B^T d; at the image's left / right edge d0 / d3 is the
-                        // convolution's zero padding, which only changes the coefficients of v0 / v3
-                        const f32x4* src = pt + (prow * LW + (r16 & 7)) * 4;
-                        const int rot = (kq + 2 * (prow & 1)) & 3;
-                        const f32x4 xa = src[rot], xb = src[4 + rot], xc = src[8 + rot];
-                        v[0][j] = up_a0 * xa + up_b0 * xb - 0.25f * xc;
-                        v[1][j] = 0.25f * (xa + xc) + 1.5f * xb;
-                        v[2][j] = 0.25f * (xc - xa);
-                        v[3][j] = 0.25f * xa + up_b3 * xb + up_c3 * xc;
+                        const f32x4* src = pt + ((prow * 4) * 8 + (r16 & 7)) * 4 + ((kq + 2 * (prow & 1)) & 3);
+                        v[0][j] = src[0]; v[1][j] = src[32]; v[2][j] = src[64]; v[3][j] = src[96];
                     }
                 }
                 if (FCO * FPX == 1) {
@@ -458,7 +458,8 @@ int sbgm_conv_lds_gn_chunks(const ConvParams& p, const ConvTile& cfg) {
 size_t sbgm_conv_lds_bytes(const ConvTile& cfg, int in_mode) {
     const int TH = 4 * (cfg.wino ? 2 * cfg.fpx : cfg.fpx);
     const int nbuf = cfg.lds == 2 ? 2 : 1;
-    size_t quads = ((size_t)(cfg.wino ? 12 : 9) * 16 * cfg.fco * 4 + (size_t)(TH + 2) * (cfg.wino ? 19 : 18) * 4) * nbuf;
+    const size_t patch = in_mode == 2 ? (size_t)(TH + 2) * 32 : (size_t)(TH + 2) * (cfg.wino ? 19 : 18);
+    size_t quads = ((size_t)(cfg.wino ? 12 : 9) * 16 * cfg.fco * 4 + patch * 4) * nbuf;
     if (in_mode == 2) quads += (size_t)(TH / 2 + 2) * 10 * 4 * nbuf;
     return quads * 16;
 }
