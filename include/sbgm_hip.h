@@ -256,6 +256,15 @@ int sbgm_batchnorm_train_apply(const float* x, float* y, const float* gamma, con
                                float eps, float momentum, void* stats_ws, double n_total, float* mean_rstd_out, void* stream);
 /* Core of nn.MultiheadAttention between in_proj and out_proj: qkv [B,S,3C] -> [B,S,C].  score_unet.py:142 */
 int sbgm_mha_core_fwd(const float* qkv, float* out, int B, int S, int C, int heads, void* stream);
+/* The per-token halves of ImageSelfAttention (score_unet.py:141-145) as single launches over token tiles, C in {64,128,256,512}:
+ *   sbgm_attn_qkv_fwd : qkv[M][3C] = LayerNorm(x; ln_gamma, ln_beta) . in_proj_weight^T + in_proj_bias          (self.ln1 + mha in_proj)
+ *   sbgm_attn_tail_fwd: h = x + att . out_proj^T + b_out;  out = h + ff[2](GELU(ff[0](LayerNorm(h))))           (:142-145)
+ * Weights are sbgm_conv_pack_weight images of the [Cout][C][1][1] matrices; `out` may alias `x`, not `att`. */
+int sbgm_attn_qkv_fwd(const float* x, const float* ln_gamma, const float* ln_beta, const float* w_in_packed, const float* b_in,
+                      float* qkv, int M, int C, float eps, void* stream);
+int sbgm_attn_tail_fwd(const float* att, const float* x, const float* w_out_packed, const float* b_out, const float* ln_gamma,
+                       const float* ln_beta, const float* w_ff1_packed, const float* b_ff1, const float* w_ff2_packed,
+                       const float* b_ff2, float* out, int M, int C, float eps, void* stream);
 /* SinusoidalEmbedding (+ label embedding) -> SiLU -> Linear, for one projection.  score_unet.py:41-45, :377-381 */
 int sbgm_time_proj_fwd(const float* t, const int64_t* y, const float* label_emb, const float* freqs, const float* weight,
                        const float* bias, float* out, float* emb_ws /* [B,D] silu(emb) */, float* emb_raw /* [B,D] or NULL */,

@@ -159,6 +159,15 @@ int sbgm_batchnorm_train_fwd(const float* x, float* y, const float* gamma, const
 int sbgm_mha_core_fwd(const float* qkv, float* out, int B, int S, int C, int heads, void* stream) {
     return sbgm_launch_mha_core(qkv, out, B, S, C, heads, ST);
 }
+int sbgm_attn_qkv_fwd(const float* x, const float* ln_gamma, const float* ln_beta, const float* w_in_packed, const float* b_in,
+                      float* qkv, int M, int C, float eps, void* stream) {
+    return sbgm_launch_attn_in(x, ln_gamma, ln_beta, w_in_packed, b_in, qkv, M, C, eps, ST);
+}
+int sbgm_attn_tail_fwd(const float* att, const float* x, const float* w_out_packed, const float* b_out, const float* ln_gamma,
+                       const float* ln_beta, const float* w_ff1_packed, const float* b_ff1, const float* w_ff2_packed,
+                       const float* b_ff2, float* out, int M, int C, float eps, void* stream) {
+    return sbgm_launch_attn_out(att, x, w_out_packed, b_out, ln_gamma, ln_beta, w_ff1_packed, b_ff1, w_ff2_packed, b_ff2, out, M, C, eps, ST);
+}
 int sbgm_time_proj_fwd(const float* t, const int64_t* y, const float* label_emb, const float* freqs, const float* weight,
                        const float* bias, float* out, float* emb_ws, float* emb_raw, int B, int D, int ch, void* stream) {
     TimeEmbedArgs a{};

@@ -504,6 +504,21 @@ int sbgm_model::conv(const ConvGeom& g, ConvParams p, hipStream_t st) {
 // y = h + FF(LN2(h)),  h = x + MHA(LN1(x))   over tokens [B*S, C]  (score_unet.py:136-148); in place on x
 int sbgm_model::attention(const AttnW& a, float* x, int B, int S, hipStream_t st) {
     const int C = a.C, M = B * S;
+    static const bool no_fused = getenv("SBGM_NO_FUSED_ATTENTION") != nullptr;
+    // Token-tile kernels when there are enough 16-token tiles to give every CU one (3 launches: LN1 + in_proj | core | out_proj +
+    // residual + LN2 + FF + residual).  Deep levels (few tokens, 256-512 channels) are bound by streaming 1-6 MB of weights: there
+    // the separate GEMMs, which split the OUTPUT CHANNELS over the chip, stay faster (measured: 512 tokens x 512 channels 90 us
+    // per fused kernel on 32 workgroups vs ~8 us per GEMM).
+    if (!no_fused && sbgm_attn_tokens_supported(C) && M >= 256 * 16) {
+        float* qkv = wsalloc((size_t)M * 3 * C);
+        if (!qkv) return 1;
+        float* att = wsalloc((size_t)M * C);
+        if (!att) return 1;
+        if (sbgm_launch_attn_in(x, a.ln1g->dev, a.ln1b->dev, a.inw->dev, a.inb->dev, qkv, M, C, LN_EPS, st)) return 1;
+        if (sbgm_launch_mha_core(qkv, att, B, S, C, cfg.n_heads, st)) return 1;
+        return sbgm_launch_attn_out(att, x, a.outw->dev, a.outb->dev, a.ln2g->dev, a.ln2b->dev, a.f1w->dev, a.f1b->dev, a.f2w->dev,
+                                    a.f2b->dev, x, M, C, LN_EPS, st);
+    }
     float* n1 = wsalloc((size_t)M * C);
     if (!n1) return 1;
     float* qkv = wsalloc((size_t)M * 3 * C);

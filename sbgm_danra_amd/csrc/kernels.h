@@ -157,6 +157,13 @@ int sbgm_launch_batchnorm_bwd_apply(const float* x, const float* dy, const float
 
 // ---- attention.hip -------------------------------------------------------------------------------------
 int sbgm_launch_mha_core(const float* qkv, float* out, int B, int S, int C, int heads, hipStream_t st);
+// attn_tokens.hip: the per-token halves of an attention block, one launch each (C in {64, 128, 256, 512})
+int sbgm_attn_tokens_supported(int C);
+int sbgm_launch_attn_in(const float* x, const float* ln_g, const float* ln_b, const float* w_packed, const float* bias, float* qkv,
+                        int M, int C, float eps, hipStream_t st);
+int sbgm_launch_attn_out(const float* att, const float* x, const float* wo, const float* bo, const float* ln_g, const float* ln_b,
+                         const float* w1, const float* b1, const float* w2, const float* b2, float* out, int M, int C, float eps,
+                         hipStream_t st);
 
 // ---- sampler.hip ---------------------------------------------------------------------------------------
 struct StepScalars {       // one row of the device-side step table

@@ -298,6 +298,46 @@ def test_mha_core(B, S, C_, heads):
     assert relerr(out.cpu(), want) < 1e-5
 
 
+def _pack_linear(w):
+    co, ci = w.shape
+    wd = w.contiguous().to(DEV)
+    packed = torch.empty(lib().sbgm_conv_packed_numel(co, 1, 1, ci), device=DEV)
+    N.check(lib().sbgm_conv_pack_weight(wd.data_ptr(), packed.data_ptr(), co, ci, 1, 1, ci, N.stream()))
+    return packed
+
+
+@pytest.mark.parametrize("M,C_", [(256, 128), (40, 64), (16, 256), (100, 512), (8192, 128), (33, 256)])
+def test_attention_token_kernels(M, C_):
+    """sbgm_attn_qkv_fwd = LayerNorm1 + in_proj, sbgm_attn_tail_fwd = out_proj + residual + LayerNorm2 + FF + residual
+    (reference sbgm/score_unet.py:141-145), ragged last token tile included"""
+    F = torch.nn.functional
+    x, att = rnd(M, C_, seed=1) * 1.5 + 0.3, rnd(M, C_, seed=2)
+    g1, b1, g2, b2 = rnd(C_, seed=3) * 0.2 + 1, rnd(C_, seed=4) * 0.2, rnd(C_, seed=5) * 0.2 + 1, rnd(C_, seed=6) * 0.2
+    sc = 1.0 / math.sqrt(C_)
+    win, bin_ = rnd(3 * C_, C_, seed=7, scale=sc), rnd(3 * C_, seed=8, scale=0.1)
+    wo, bo = rnd(C_, C_, seed=9, scale=sc), rnd(C_, seed=10, scale=0.1)
+    w1, bb1, w2, bb2 = rnd(C_, C_, seed=11, scale=sc), rnd(C_, seed=12, scale=0.1), rnd(C_, C_, seed=13, scale=sc), rnd(C_, seed=14, scale=0.1)
+    want_qkv = F.linear(F.layer_norm(x, (C_,), g1, b1, 1e-5), win, bin_)
+    h = x + F.linear(att, wo, bo)
+    want = h + F.linear(F.gelu(F.linear(F.layer_norm(h, (C_,), g2, b2, 1e-5), w1, bb1)), w2, bb2)
+    d = lambda t: t.contiguous().to(DEV)  # noqa: E731
+    xd, attd = d(x), d(att)
+    qkv = torch.full((M, 3 * C_), float("nan"), device=DEV)
+    head = [d(g1), d(b1), _pack_linear(win), d(bin_)]                       # keep the device tensors alive across the call
+    N.check(lib().sbgm_attn_qkv_fwd(xd.data_ptr(), *[t.data_ptr() for t in head], qkv.data_ptr(), M, C_, 1e-5, N.stream()))
+    assert relerr(qkv.cpu(), want_qkv) < 1e-5
+    out = torch.full((M, C_), float("nan"), device=DEV)
+    args = [d(t) for t in (wo, bo, g2, b2)] + [_pack_linear(w1), d(bb1), _pack_linear(w2), d(bb2)]
+    args[0] = _pack_linear(wo)
+    N.check(lib().sbgm_attn_tail_fwd(attd.data_ptr(), xd.data_ptr(), *[t.data_ptr() for t in args], out.data_ptr(), M, C_, 1e-5, N.stream()))
+    assert relerr(out.cpu(), want) < 1e-5
+    # in place on x (how the engine calls it)
+    N.check(lib().sbgm_attn_tail_fwd(attd.data_ptr(), xd.data_ptr(), *[t.data_ptr() for t in args], xd.data_ptr(), M, C_, 1e-5, N.stream()))
+    assert torch.equal(xd, out)
+    with pytest.raises(N.NativeError):
+        N.check(lib().sbgm_attn_qkv_fwd(xd.data_ptr(), *[t.data_ptr() for t in head], qkv.data_ptr(), M, 96, 1e-5, N.stream()))
+
+
 def test_mha_online_softmax_rescale_branch():
     """spike late keys so the running max jumps in a later key block (guide rule: force the rescale path)"""
     B, S, C_, heads = 1, 64, 64, 2
