@@ -214,6 +214,14 @@ int sbgm_conv_pack_weights_batched(const sbgm_pack_desc* desc_dev, int n, int to
  * sbgm_layernorm_bwd's dgamma/dbeta, sbgm_samplesum's output, sbgm_batchnorm_train_fwd's sums): 1 = the caller
  * hands in already-zeroed scratch and the launchers skip their own memsets.  Returns the previous value. */
 int sbgm_set_scratch_prezeroed(int on);
+/* Deferred weight-gradient layout passes.  sbgm_conv2d_wgrad[_bias] accumulates most gradients in a [tap][Cout][c_pad] slab (ws)
+ * and converts it to OIHW with a small layout launch.  With sbgm_wgrad_defer(1) in force that launch is queued instead, and
+ * sbgm_wgrad_flush runs every queued conversion as ONE launch (21 per training step of the default model): the caller keeps the
+ * queued ws / dw_oihw buffers alive and untouched until the flush, after which dw_oihw holds the gradients.  Process-wide, returns
+ * the previous value; sbgm_wgrad_flush_pending() = number of queued conversions. */
+int sbgm_wgrad_defer(int on);
+int sbgm_wgrad_flush(void* stream);
+int sbgm_wgrad_flush_pending(void);
 /* Winograd F(2,3)-along-rows weight transform for 3x3 kernels: OIHW -> U[kh][c/16][xi][Cout][16] */
 int64_t sbgm_conv_wino_packed_numel(int Cout, int c_pad);
 int sbgm_conv_wino_pack_weight(const float* w_oihw, float* packed, int Cout, int Cin, int c_pad, void* stream);

@@ -118,6 +118,9 @@ SIGNATURES = {
     "sbgm_batchnorm_bwd_reduce": (_i, [_vp] * 5 + [_i, _vp, _i, _i, _i, _vp]),
     "sbgm_batchnorm_bwd_apply": (_i, [_vp] * 6 + [_i] + [_vp] * 6 + [C.c_double, _i, _i, _i, _vp]),
     "sbgm_mha_core_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "sbgm_wgrad_defer": (_i, [_i]),
+    "sbgm_wgrad_flush": (_i, [_vp]),
+    "sbgm_wgrad_flush_pending": (_i, []),
     "sbgm_attn_qkv_fwd": (_i, [_vp] * 6 + [_i, _i, _f, _vp]),
     "sbgm_attn_tail_fwd": (_i, [_vp] * 11 + [_i, _i, _f, _vp]),
     "sbgm_time_proj_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

@@ -4,6 +4,7 @@
 // GEMM, the normalisation / attention / resampling backward passes and the small reductions.
 // First version: correct and parity-tested; only the weight-gradient kernel is on the MFMA pipe.
 #include <cstdlib>
+#include <vector>
 #include "common.h"
 #include "kernels.h"
 
@@ -457,6 +458,42 @@ __global__ void unpack_wgrad_kernel(const float* __restrict__ dwp, float* __rest
         const int ci = (int)((i / taps) % Cin);
         const int co = (int)(i / ((size_t)taps * Cin));
         dw[i] = dwp[((size_t)tap * Cout + co) * Cs + ci];
+    }
+}
+
+// Deferred form: every slab -> OIHW pass of a backward sweep in ONE launch.  The descriptors travel by value in the kernel
+// arguments (no device table to fill under stream capture); a block finds its slab by the block-start table.
+constexpr int UNPACK_MAX = 48;
+struct UnpackDesc { const float* src; float* dst; int Cout, Cin, Cs, taps; };      // taps < 0: stem slab with KH = -taps
+struct UnpackTable {
+    UnpackDesc d[UNPACK_MAX];
+    int start[UNPACK_MAX + 1];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void unpack_wgrad_batched_kernel(const UnpackTable t) {
+    int k = 0;
+    while (k + 1 < t.n && (int)blockIdx.x >= t.start[k + 1]) ++k;
+    const UnpackDesc d = t.d[k];
+    const int nblk = t.start[k + 1] - t.start[k], blk = blockIdx.x - t.start[k];
+    if (d.taps < 0) {
+        const int KH = -d.taps;
+        const size_t total = (size_t)d.Cout * d.Cin * KH * 8;
+        for (size_t i = (size_t)blk * blockDim.x + threadIdx.x; i < total; i += (size_t)nblk * blockDim.x) {
+            const int kw = (int)(i & 7);
+            const int kh = (int)((i >> 3) % KH);
+            const int ci = (int)((i / ((size_t)8 * KH)) % d.Cin);
+            const int co = (int)(i / ((size_t)8 * KH * d.Cin));
+            d.dst[i] = d.src[(((size_t)kh * d.Cout + co) * 8 + kw) * 8 + ci];
+        }
+        return;
+    }
+    const size_t total = (size_t)d.Cout * d.Cin * d.taps;
+    for (size_t i = (size_t)blk * blockDim.x + threadIdx.x; i < total; i += (size_t)nblk * blockDim.x) {
+        const int tap = (int)(i % d.taps);
+        const int ci = (int)((i / d.taps) % d.Cin);
+        const int co = (int)(i / ((size_t)d.taps * d.Cin));
+        d.dst[i] = d.src[((size_t)tap * d.Cout + co) * d.Cs + ci];
     }
 }
 
@@ -1077,6 +1114,53 @@ __global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ 
 }  // namespace
 
 // ---- launchers -----------------------------------------------------------------------------------------------------
+// Deferred slab -> OIHW passes (sbgm_wgrad_defer / sbgm_wgrad_flush in the C ABI): while deferral is on, sbgm_launch_conv_wgrad
+// queues its layout pass instead of launching it; the flush at the end of the backward sweep runs all of them as one kernel.
+// The caller keeps every queued slab alive and untouched until the flush.  Process-wide, like the prezeroed switch.
+int sbgm_wgrad_deferred = 0;
+static std::vector<UnpackDesc> g_unpack_queue;
+
+static int unpack_or_queue(const float* src, float* dst, int Cout, int Cin, int Cs, int taps, hipStream_t st) {
+    if (sbgm_wgrad_deferred) {
+        g_unpack_queue.push_back(UnpackDesc{src, dst, Cout, Cin, Cs, taps});
+        return 0;
+    }
+    const size_t total = (size_t)Cout * Cin * (taps < 0 ? -taps * 8 : taps);
+    if (taps < 0) hipLaunchKernelGGL(unpack_wgrad_stem_kernel, dim3(stream_blocks(total)), dim3(256), 0, st, src, dst, Cout, Cin, -taps);
+    else hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(stream_blocks(total)), dim3(256), 0, st, src, dst, Cout, Cin, Cs, taps);
+    SBGM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sbgm_wgrad_pending() { return (int)g_unpack_queue.size(); }
+
+int sbgm_launch_wgrad_flush(hipStream_t st) {
+    size_t i = 0;
+    const size_t n = g_unpack_queue.size();
+    while (i < n) {
+        UnpackTable t{};
+        int nb = 0;
+        t.n = 0;
+        for (; i < n && t.n < UNPACK_MAX; ++i) {
+            const UnpackDesc& d = g_unpack_queue[i];
+            const size_t total = (size_t)d.Cout * d.Cin * (d.taps < 0 ? -d.taps * 8 : d.taps);
+            t.d[t.n] = d;
+            t.start[t.n] = nb;
+            nb += (int)std::max<size_t>(1, std::min<size_t>((total + 1023) / 1024, 256));          // >= 4 elements per thread
+            ++t.n;
+        }
+        t.start[t.n] = nb;
+        hipLaunchKernelGGL(unpack_wgrad_batched_kernel, dim3(nb), dim3(256), 0, st, t);
+        if (hipGetLastError() != hipSuccess) {
+            g_unpack_queue.clear();
+            sbgm_set_error("wgrad_flush: launch failed");
+            return 1;
+        }
+    }
+    g_unpack_queue.clear();
+    return 0;
+}
+
 int sbgm_launch_conv_wgrad(const float* dy, const float* x, float* dw_oihw, float* dwp_ws, int B, int H, int W, int Cs, int Cin,
                            int Cout, int KH, int KW, int S, int PAD, hipStream_t st, float* dbias) {
     SBGM_CHECK(Cout % 64 == 0, "wgrad: Cout=%d must be a multiple of 64", Cout);
@@ -1116,11 +1200,7 @@ int sbgm_launch_conv_wgrad(const float* dy, const float* x, float* dw_oihw, floa
             hipLaunchKernelGGL(conv3x3_wgrad_lds_kernel<8>, grid_lds, dim3(WG_THREADS), (size_t)(WG_DY_FLOATS + WgTile<8>::X_FLOATS) * 4, st,
                                dy, x, dwp_ws, dbias, B, H, W, Cs, Cout, tpw, (uint32_t)dy_b, (uint32_t)x_b, direct, Cin);
         SBGM_LAUNCH_CHECK();
-        if (!direct) {
-            hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(stream_blocks((size_t)Cout * Cin * KH * KW)), dim3(256), 0, st, dwp_ws, dw_oihw,
-                               Cout, Cin, Cs, KH * KW);
-            SBGM_LAUNCH_CHECK();
-        }
+        if (!direct) return unpack_or_queue(dwp_ws, dw_oihw, Cout, Cin, Cs, KH * KW, st);
         return 0;
     }
     const bool stem = Cs == 8 && KW == 8;
@@ -1149,15 +1229,8 @@ int sbgm_launch_conv_wgrad(const float* dy, const float* x, float* dw_oihw, floa
         hipLaunchKernelGGL(conv_tap_wgrad_lds_kernel, grid_lds, dim3(WG_THREADS), lds, st, dy, x, dwp_ws, dbias, tg, Cs, Cout, tpw,
                            (uint32_t)dy_b, (uint32_t)x_b, direct, Cin);
         SBGM_LAUNCH_CHECK();
-        if (stem) {
-            hipLaunchKernelGGL(unpack_wgrad_stem_kernel, dim3(stream_blocks((size_t)Cout * Cin * KH * KW)), dim3(256), 0, st, dwp_ws, dw_oihw,
-                               Cout, Cin, KH);
-            SBGM_LAUNCH_CHECK();
-        } else if (!direct && !aliased) {
-            hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(stream_blocks((size_t)Cout * Cin * KH * KW)), dim3(256), 0, st, dwp_ws, dw_oihw, Cout,
-                               Cin, Cs, KH * KW);
-            SBGM_LAUNCH_CHECK();
-        }
+        if (stem) return unpack_or_queue(dwp_ws, dw_oihw, Cout, Cin, Cs, -KH, st);
+        if (!direct && !aliased) return unpack_or_queue(dwp_ws, dw_oihw, Cout, Cin, Cs, KH * KW, st);
         return 0;
     }
     if (!sbgm_scratch_prezeroed) { if (sbgm_zero_async(dwp_ws, n * 4, st)) return 1; }
@@ -1166,10 +1239,7 @@ int sbgm_launch_conv_wgrad(const float* dy, const float* x, float* dw_oihw, floa
     if (fci == 4) SBGM_WG(4); else if (fci == 2) SBGM_WG(2); else SBGM_WG(1);
 #undef SBGM_WG
     SBGM_LAUNCH_CHECK();
-    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(stream_blocks((size_t)Cout * Cin * KH * KW)), dim3(256), 0, st, dwp_ws, dw_oihw, Cout,
-                       Cin, Cs, KH * KW);
-    SBGM_LAUNCH_CHECK();
-    return 0;
+    return unpack_or_queue(dwp_ws, dw_oihw, Cout, Cin, Cs, KH * KW, st);
 }
 
 int sbgm_launch_colsum(const float* x, const float* y, float* out, int M, int C, hipStream_t st) {

@@ -125,6 +125,13 @@ int sbgm_set_scratch_prezeroed(int on) {
     sbgm_scratch_prezeroed = on ? 1 : 0;
     return prev;
 }
+int sbgm_wgrad_defer(int on) {
+    const int prev = sbgm_wgrad_deferred;
+    sbgm_wgrad_deferred = on ? 1 : 0;
+    return prev;
+}
+int sbgm_wgrad_flush(void* stream) { return sbgm_launch_wgrad_flush(ST); }
+int sbgm_wgrad_flush_pending(void) { return sbgm_wgrad_pending(); }
 
 int sbgm_conv2d_tune(const sbgm_conv_args* a, int* tile, void* stream) {
     SBGM_CHECK(a && tile && a->x && a->w_packed && a->out, "conv2d_tune: null argument");

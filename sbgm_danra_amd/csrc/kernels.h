@@ -62,6 +62,9 @@ int sbgm_launch_conv(const ConvGeom& g, ConvParams p, const ConvTile& cfg, float
 // When set, the launchers below trust that their atomically accumulated scratch (weight-gradient slab, norm-backward sums)
 // arrives zeroed and skip their own memsets (the training path zeroes one pooled buffer per step instead of ~75 small ones).
 extern int sbgm_scratch_prezeroed;
+extern int sbgm_wgrad_deferred;                 // backward.hip: queue the slab -> OIHW passes for sbgm_launch_wgrad_flush
+int sbgm_wgrad_pending();
+int sbgm_launch_wgrad_flush(hipStream_t st);
 
 // ---- conv_wino.hip: 3x3 stride-1 pad-1 convolution, 1-D Winograd F(2,3) along rows ------------------------------------
 size_t sbgm_wino_packed_floats(int Cout, int cs);

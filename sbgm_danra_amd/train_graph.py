@@ -48,15 +48,26 @@ def _splitk_ws(dev):
 # Backward scratch that is accumulated with atomics (weight-gradient slabs, norm-backward sums) comes out of ONE buffer that
 # forward_train zeroes once per step; slices are handed out sequentially and never reused before the next forward, so every
 # slice is still zero when its kernel runs (a second backward through the same graph simply takes fresh slices).
+# Only the part that was handed out is re-zeroed: everything past the step's offset is still zero from the allocation.  Under
+# stream capture the zeroing is recorded with a fixed extent (the high-water mark of earlier steps); slices past it come from
+# fresh tensors, so a replay never sees a stale slab.
 _ZERO_FLOATS = 32 << 20
-_ZERO = {}             # device -> [buffer, offset]
+_ZERO = {}             # device -> [buffer, offset, high-water mark, usable extent of this step]
 
 
 def _zero_reset(dev):
+    if _L().sbgm_wgrad_flush_pending():           # a backward pass that raised before its end-of-pass callback: finish it
+        N.check(_L().sbgm_wgrad_flush(_st()))
+    _FLUSH_QUEUED[0] = False
     z = _ZERO.get(dev)
     if z is None:
-        z = _ZERO[dev] = [torch.empty(_ZERO_FLOATS, device=dev), 0]
-    z[0].zero_()
+        z = _ZERO[dev] = [torch.zeros(_ZERO_FLOATS, device=dev), 0, 0, _ZERO_FLOATS, False]
+    capturing = dev.type == "cuda" and torch.cuda.is_current_stream_capturing()
+    z[4] = z[4] or capturing               # replays of captured steps dirty the pool behind Python's back: from then on the
+    dirty = z[2] if z[4] else z[1]         # whole high-water prefix is re-zeroed, not just this process's last step
+    if dirty:
+        z[0][:dirty].zero_()
+    z[3] = z[2] if capturing else _ZERO_FLOATS
     z[1] = 0
     _GRAD[dev] = [torch.zeros(_GRAD_FLOATS, device=dev), 0]
 
@@ -170,11 +181,44 @@ def _zeros(n, dev):
     """n zeroed floats: a slice of the step's pool (second value True -> the launcher may skip its own memset) or a fresh tensor"""
     z = _ZERO.get(dev)
     n_al = (n + 63) // 64 * 64
-    if z is None or z[1] + n_al > _ZERO_FLOATS:
+    if z is None or z[1] + n_al > z[3]:
         return torch.zeros(n, device=dev), False
     out = z[0][z[1]: z[1] + n]
     z[1] += n_al
+    z[2] = max(z[2], z[1])
     return out, True
+
+
+# Slab -> OIHW layout passes of the weight gradients are queued during a backward pass and run as one launch at its end
+# (autograd's end-of-pass callback).  Only slabs from the step's pool are queued: they stay alive and untouched until the next
+# forward.  Until the callback has run, the affected `.grad` views hold zeros (gradient hooks on conv weights would see that).
+_DEFER_UNPACK = [True]
+_FLUSH_QUEUED = [False]
+
+
+def _flush_wgrad():
+    _FLUSH_QUEUED[0] = False
+    if _L().sbgm_wgrad_flush_pending():
+        N.check(_L().sbgm_wgrad_flush(_st()))
+
+
+class _deferred_unpack:
+    def __init__(self, on):
+        self.on = on and _DEFER_UNPACK[0]
+
+    def __enter__(self):
+        if self.on:
+            self.prev = _L().sbgm_wgrad_defer(1)
+
+    def __exit__(self, *exc):
+        if self.on:
+            _L().sbgm_wgrad_defer(self.prev)
+            if not _FLUSH_QUEUED[0] and _L().sbgm_wgrad_flush_pending():
+                try:
+                    torch.autograd.Variable._execution_engine.queue_callback(_flush_wgrad)
+                    _FLUSH_QUEUED[0] = True
+                except RuntimeError:                       # not inside a backward pass (a direct .backward() call on the Function)
+                    _flush_wgrad()
 
 
 class _prezeroed:
@@ -338,18 +382,21 @@ class ConvFn(torch.autograd.Function):
             if k == 1 and cs == cin and cs % 64 == 0 and cout % 64 == 0:
                 # 1x1 / linear: the partial-sum slab has the OIHW layout, so the (zeroed) gradient itself is the workspace
                 dw, pooled = _pgrad(arena, w, True)
-                ws = dw
+                ws, defer = dw, False
             else:
-                dw, _ = _pgrad(arena, w, False)
+                dw, in_arena = _pgrad(arena, w, False)
                 ws, pooled = _zeros(k * k * cout * cs, x.device)
+                # the layout pass may run at the end of the backward sweep only when nothing consumes dw before that: an arena
+                # slice becomes p.grad as it is; a fresh tensor may be added to a live .grad by AccumulateGrad right away
+                defer = pooled and in_arena
             if want_db and pooled:                               # bias gradient as a by-product of the weight-gradient sweep
                 db, _ = _pgrad(arena, bias, True)                # a returned gradient: never a slice of the re-zeroed scratch pool
-                with _prezeroed(True):
+                with _prezeroed(True), _deferred_unpack(ws is not dw and defer):
                     N.check(_L().sbgm_conv2d_wgrad_bias(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), B, H, W,
                                                         cs, cin, cout, k, k, stride, pad, _st()))
                 want_db = False
             else:
-                with _prezeroed(pooled):
+                with _prezeroed(pooled), _deferred_unpack(ws is not dw and defer):
                     N.check(_L().sbgm_conv2d_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), ws.data_ptr(), B, H, W, cs, cin, cout, k, k,
                                                    stride, pad, _st()))
         if want_db:
