@@ -277,6 +277,13 @@ int sbgm_attn_tail_fwd(const float* att, const float* x, const float* w_out_pack
 int sbgm_time_proj_fwd(const float* t, const int64_t* y, const float* label_emb, const float* freqs, const float* weight,
                        const float* bias, float* out, float* emb_ws /* [B,D] silu(emb) */, float* emb_raw /* [B,D] or NULL */,
                        int B, int D, int ch, void* stream);
+/* Several projections in one launch pair (embeddings | projections): n_emb embeddings (label_emb is added to embedding 0), n_proj
+ * projections, projection i reads embedding emb_index[i] and writes outs[i] [B, chs[i]].  emb_ws / emb_raw: [n_emb][B][D]
+ * (silu(emb) / emb; emb_raw may be NULL).  n_emb <= 8, n_proj <= 16.  The encoder's 5 projections share one embedding
+ * (score_unet.py:301-308); each decoder block has its own (:606-609). */
+int sbgm_time_proj_multi_fwd(const float* t, const int64_t* y, const float* label_emb, const float* const* freqs, int n_emb,
+                             const float* const* weights, const float* const* biases, float* const* outs, const int* chs,
+                             const int* emb_index, int n_proj, float* emb_ws, float* emb_raw, int B, int D, void* stream);
 /* final_layer.conv (3x3, C->1) + division by marginal_prob_std(t).  score_unet.py:489, :876-877.
  * w_tap_c from sbgm_cout1_pack_weight; t NULL = no division. */
 int sbgm_cout1_pack_weight(const float* w_oihw, float* w_tap_c, int C, void* stream);

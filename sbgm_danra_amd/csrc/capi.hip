@@ -184,6 +184,21 @@ int sbgm_time_proj_fwd(const float* t, const int64_t* y, const float* label_emb,
     a.emb_ws = emb_ws; a.B = B; a.D = D;
     return sbgm_launch_time_embed(a, ST);
 }
+int sbgm_time_proj_multi_fwd(const float* t, const int64_t* y, const float* label_emb, const float* const* freqs, int n_emb,
+                             const float* const* weights, const float* const* biases, float* const* outs, const int* chs,
+                             const int* emb_index, int n_proj, float* emb_ws, float* emb_raw, int B, int D, void* stream) {
+    SBGM_CHECK(t && freqs && weights && biases && outs && chs && emb_index && emb_ws, "time_proj_multi: null argument");
+    SBGM_CHECK(n_emb >= 1 && n_emb <= 8 && n_proj >= 1 && n_proj <= 16, "time_proj_multi: n_emb=%d (1..8), n_proj=%d (1..16)", n_emb, n_proj);
+    TimeEmbedArgs a{};
+    a.t = t; a.y = y; a.label_emb = label_emb; a.n_emb = n_emb; a.n_proj = n_proj;
+    for (int i = 0; i < n_emb; ++i) a.freqs[i] = freqs[i];
+    for (int i = 0; i < n_proj; ++i) {
+        SBGM_CHECK(emb_index[i] >= 0 && emb_index[i] < n_emb, "time_proj_multi: emb_index[%d]=%d", i, emb_index[i]);
+        a.proj[i] = TimeProj{weights[i], biases[i], outs[i], chs[i], emb_index[i]};
+    }
+    a.emb_ws = emb_ws; a.emb_raw = emb_raw; a.B = B; a.D = D;
+    return sbgm_launch_time_embed(a, ST);
+}
 int sbgm_cout1_pack_weight(const float* w_oihw, float* w_tap_c, int C, void* stream) {
     return sbgm_launch_pack_cout1_weight(w_oihw, w_tap_c, C, ST);
 }

@@ -666,6 +666,54 @@ class TimeProjFn(torch.autograd.Function):
         return None, None, dtable, None, dW, db
 
 
+class TimeProjMultiFn(torch.autograd.Function):
+    """n_proj projections of n_emb time embeddings in one launch pair (instead of one pair per projection):
+    apply(t, y, table, emb_index (tuple), n_emb, *freqs[n_emb], *weights[n_proj], *biases[n_proj]) -> n_proj tensors [B, ch_i]"""
+
+    @staticmethod
+    def forward(ctx, t, y, table, emb_index, n_emb, *rest):
+        n_proj = len(emb_index)
+        freqs, weights, biases = rest[:n_emb], rest[n_emb:n_emb + n_proj], rest[n_emb + n_proj:]
+        B, D = t.numel(), weights[0].shape[1]
+        dev = t.device
+        outs = [torch.empty(B, w.shape[0], device=dev) for w in weights]
+        semb, raw = torch.empty(n_emb, B, D, device=dev), torch.empty(n_emb, B, D, device=dev)
+        arr = lambda ts: (C.c_void_p * len(ts))(*[x.data_ptr() for x in ts])                 # noqa: E731
+        N.check(_L().sbgm_time_proj_multi_fwd(t.data_ptr(), N.ptr(y), N.ptr(table) if y is not None else None, arr(freqs), n_emb,
+                                              arr(weights), arr(biases), arr(outs), (C.c_int * n_proj)(*[w.shape[0] for w in weights]),
+                                              (C.c_int * n_proj)(*emb_index), n_proj, semb.data_ptr(), raw.data_ptr(), B, D, _st()))
+        ctx.save_for_backward(semb, raw, y if y is not None else torch.empty(0), table if table is not None else torch.empty(0),
+                              *weights, *biases)
+        ctx.meta = (tuple(emb_index), n_emb, n_proj, y is not None)
+        ctx.arena = _ACTIVE_ARENA[0]
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        emb_index, n_emb, n_proj, has_y = ctx.meta
+        semb, raw, y, table = ctx.saved_tensors[:4]
+        weights, biases = ctx.saved_tensors[4:4 + n_proj], ctx.saved_tensors[4 + n_proj:]
+        B, D = semb.shape[1], semb.shape[2]
+        demb = torch.zeros(B, D, device=semb.device) if has_y else None          # only embedding 0 carries the label embedding
+        dWs, dbs = [None] * n_proj, [None] * n_proj
+        for i, dout in enumerate(douts):
+            if dout is None:
+                continue
+            dout = dout.contiguous()
+            dWs[i], dbs[i] = _pgrad(ctx.arena, weights[i], False)[0], _pgrad(ctx.arena, biases[i], False)[0]
+            e = emb_index[i]
+            N.check(_L().sbgm_time_proj_bwd(dout.data_ptr(), weights[i].data_ptr(), semb[e].data_ptr(), raw[e].data_ptr(),
+                                            dWs[i].data_ptr(), dbs[i].data_ptr(), N.ptr(demb) if e == 0 else None, B, D,
+                                            weights[i].shape[0], _st()))
+        dtable = None
+        if has_y:
+            dtable, was_zero = _pgrad(ctx.arena, table, True)
+            if not was_zero:
+                dtable.zero_()
+            N.check(_L().sbgm_label_emb_bwd(demb.data_ptr(), y.data_ptr(), dtable.data_ptr(), B, D, _st()))
+        return (None, None, dtable, None, None) + (None,) * n_emb + tuple(dWs) + tuple(dbs)
+
+
 class Cout1Fn(torch.autograd.Function):
     """final_layer.conv (3x3, C -> 1) followed by the division by sigma(t) (t None: no division): NHWC a -> NCHW [B,1,H,W]"""
 
@@ -798,7 +846,9 @@ def encoder_forward(enc, x, t, y, cond, lsm, topo):
     if y is not None and tlabel is None:
         raise ValueError("y given but the model has no label embedding")
     x0 = _pack_inputs(x, lsm, topo, cond, _pad_c(enc.input_channels))
-    tb = [_tproj(t, y if tlabel is not None else None, tlabel, enc.sinusoidal_embedding, enc.time_projection_layers[i]) for i in range(5)]
+    seqs = [enc.time_projection_layers[i][1] for i in range(5)]               # one embedding, five SiLU -> Linear heads (:301-308)
+    tb = TimeProjMultiFn.apply(t, y if tlabel is not None else None, tlabel, (0,) * 5, 1, enc.sinusoidal_embedding.W,
+                               *[q.weight for q in seqs], *[q.bias for q in seqs])
     f1 = ConvFn.apply(x0, enc.conv1.weight, None, None, tb[0], 2, 3)                    # conv1 + time bias (:312-316)
     h = _bn(ConvFn.apply(f1, enc.conv2.weight, None, None, None, 2, 3), enc.bn1)
     fmaps = [f1]
@@ -823,8 +873,9 @@ def _upsampled(blk, h):           # (A) of DecoderBlock: resize-conv (default) o
     return conv_transpose2x(h, blk.transpose)
 
 
-def decoder_block_forward(blk, cur, skip, t):
-    """DecoderBlock.forward (reference score_unet.py:559-627) for a block WITH norms: NHWC in, NHWC out"""
+def decoder_block_forward(blk, cur, skip, t, tbd=None):
+    """DecoderBlock.forward (reference score_unet.py:559-627) for a block WITH norms: NHWC in, NHWC out.  tbd: the block's time
+    projection when the caller already computed it (decoder_forward batches the four blocks' projections)"""
     group = blk.norm_kind == "group"
     G1 = max(1, min(blk.gn_groups, blk.input_channels)) if group else blk.input_channels
     G2 = max(1, min(blk.gn_groups, blk.output_channels)) if group else blk.output_channels
@@ -834,7 +885,8 @@ def decoder_block_forward(blk, cur, skip, t):
         raise NotImplementedError(f"decoder activation {type(blk.activation).__name__} not implemented natively")
     a = GroupNormFn.apply(_upsampled(blk, cur), *g(blk.norm1), None, None, N.NONE, G1, 1e-5)
     c2 = ConvFn.apply(a, blk.conv.weight, blk.conv.bias, None, None, 1, 1)
-    tbd = None if t is None else _tproj(t, None, None, blk.sinusoidal_embedding, blk.time_projection_layer)
+    if tbd is None and t is not None:
+        tbd = _tproj(t, None, None, blk.sinusoidal_embedding, blk.time_projection_layer)
     out = GroupNormFn.apply(c2, *g(blk.norm2), skip, tbd, act, G2, 1e-5)
     if blk.compute_attn:
         out = _attention(blk.attention, out)
@@ -844,8 +896,14 @@ def decoder_block_forward(blk, cur, skip, t):
 def decoder_forward(dec, fmaps, t):
     """Decoder.forward up to (not including) final_layer.conv: the 4 residual blocks and the final block's upsampling convolution"""
     cur = fmaps[4]
-    for i, blk in enumerate(dec.residual_layers):
-        cur = decoder_block_forward(blk, cur, fmaps[3 - i], t)
+    blocks = list(dec.residual_layers)
+    tbs = [None] * len(blocks)
+    if t is not None and len(blocks) <= 8:                   # every block has its own embedding + projection (:606-609)
+        n = len(blocks)
+        tbs = TimeProjMultiFn.apply(t, None, None, tuple(range(n)), n, *[b.sinusoidal_embedding.W for b in blocks],
+                                    *[b.time_projection_layer[1].weight for b in blocks], *[b.time_projection_layer[1].bias for b in blocks])
+    for i, blk in enumerate(blocks):
+        cur = decoder_block_forward(blk, cur, fmaps[3 - i], t, tbs[i])
     return _upsampled(dec.final_layer, cur)
 
 
