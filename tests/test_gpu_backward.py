@@ -172,6 +172,61 @@ def test_time_projection_backward(with_y):
         assert maxrel(tabd.grad.cpu(), tabr.grad) < GT
 
 
+def test_time_projection_multi_equals_single_projections():
+    """TimeProjMultiFn (one launch pair for several projections) == one TimeProjFn per projection: outputs and every gradient,
+    for the encoder's pattern (5 heads on one embedding + label embedding) and the decoder's (4 embeddings, one head each)"""
+    B, D = 4, 256
+    t, y = torch.tensor([1e-3, 0.2, 0.7, 1.0]).cuda(), torch.tensor([1, 4, 0, 2]).cuda()
+    chs = [64, 64, 128, 256, 512]
+    for emb_index, n_emb, with_y in (((0,) * 5, 1, True), ((0, 1, 2, 3), 4, False)):
+        n = len(emb_index)
+        freqs = [rnd(D // 2, seed=10 + i).cuda() * 30 for i in range(n_emb)]
+        ws = [rnd(chs[i], D, seed=20 + i) * 0.05 for i in range(n)]
+        bs = [rnd(chs[i], seed=30 + i) for i in range(n)]
+        gos = [rnd(B, chs[i], seed=40 + i).cuda() for i in range(n)]
+        table = rnd(5, D, seed=3)
+        w1, b1, tab1 = [leaf(w, True) for w in ws], [leaf(b, True) for b in bs], leaf(table, True)
+        single = [T.TimeProjFn.apply(t, y if with_y else None, tab1 if with_y else None, freqs[emb_index[i]], w1[i], b1[i]) for i in range(n)]
+        torch.autograd.backward(single, gos)
+        w2, b2, tab2 = [leaf(w, True) for w in ws], [leaf(b, True) for b in bs], leaf(table, True)
+        multi = T.TimeProjMultiFn.apply(t, y if with_y else None, tab2 if with_y else None, emb_index, n_emb, *freqs, *w2, *b2)
+        torch.autograd.backward(multi, gos)
+        for i in range(n):
+            assert torch.equal(multi[i], single[i])
+            assert torch.equal(w2[i].grad, w1[i].grad) and torch.equal(b2[i].grad, b1[i].grad)
+        if with_y:
+            assert maxrel(tab2.grad.cpu(), tab1.grad.cpu()) < 1e-6           # atomics: the accumulation order may differ
+
+
+def test_deferred_weight_gradient_layout_passes():
+    """sbgm_wgrad_defer / sbgm_wgrad_flush: queued slab -> OIHW conversions (3x3, 1x1 with channel padding, the 8-channel stem),
+    flushed as one launch, give exactly the gradients of the immediate form"""
+    lib = N.lib()
+    cases = [(2, 64, 16, 64, 3, 1, 1, 64), (3, 128, 8, 64, 3, 1, 1, 128), (2, 64, 16, 128, 3, 2, 1, 64), (1, 5, 32, 64, 8, 2, 3, 8),
+             (2, 64, 8, 64, 3, 1, 1, 64), (4, 64, 32, 64, 3, 1, 1, 64), (4, 64, 32, 128, 3, 2, 1, 64)]
+    keep, now, later = [], [], []
+    for defer in (0, 1):
+        prev = lib.sbgm_wgrad_defer(defer)
+        for i, (B, cin, H, cout, k, s, p, cs) in enumerate(cases):
+            oh = (H + 2 * p - k) // s + 1
+            x = torch.zeros(B, H, H, cs)
+            x[..., :cin] = rnd(B, H, H, cin, seed=i)
+            dy = rnd(B, oh, oh, cout, seed=50 + i)
+            xd, dyd = x.cuda(), dy.cuda()
+            dw, ws = torch.full((cout, cin, k, k), float("nan"), device="cuda"), torch.zeros(k * k * cout * cs, device="cuda")
+            N.check(lib.sbgm_conv2d_wgrad(dyd.data_ptr(), xd.data_ptr(), dw.data_ptr(), ws.data_ptr(), B, H, H, cs, cin, cout, k, k, s, p,
+                                          N.stream()))
+            keep += [xd, dyd, ws]
+            (later if defer else now).append(dw)
+        lib.sbgm_wgrad_defer(prev)
+    assert 2 <= lib.sbgm_wgrad_flush_pending() <= len(cases)                 # layers without a pixel split store OIHW directly
+    assert any(torch.isnan(d).any() for d in later)                          # ... the queued ones are not written yet
+    N.check(lib.sbgm_wgrad_flush(N.stream()))
+    assert lib.sbgm_wgrad_flush_pending() == 0
+    for a, b in zip(now, later):
+        assert maxrel(b.cpu(), a.cpu()) < 1e-6 and not torch.isnan(b).any()  # atomically accumulated slabs: order may differ in the last bit
+
+
 def test_final_conv_backward():
     B, Cc, H, W = 2, 64, 10, 12
     a, w, b, t, go = rnd(B, Cc, H, W), rnd(1, Cc, 3, 3, seed=1) * 0.05, rnd(1, seed=2), torch.tensor([0.05, 0.8]), rnd(B, 1, H, W, seed=3)

@@ -2,9 +2,10 @@
 # Round profile collection on the GPU box (run through gpurun from the repo root):
 #   bash tools/collect_profiles.sh r02
 # Per workload (C2 = BASELINE configs[1]: 128x128, batch 32, Euler-Maruyama;  C4 = configs[3]: 256x256, batch 16, predictor-corrector):
-# 1. bench.py (autotune -> tile table saved), the JSON line and the per-convolution HIP-event timings
+# 1. bench.py autotune -> tile table saved
 # 2. rocprofv3 --kernel-trace --stats of the same command (same tile table)          -> <tag>_<wl>_kernel_stats.csv, _step_breakdown.txt
 # 3. two PMC passes (FETCH_SIZE, WRITE_SIZE; never combined with other trace domains) -> <tag>_pmc_traffic_<wl>.json (+ source hash)
+# 4. bench.py: the JSON line (roofline.traffic from 3) and the per-convolution HIP-event timings
 # then the C3 training step (kernel trace -> <tag>_train_step_breakdown.txt, bench line).
 # Everything lands in gpurun_out/profiles_<tag>/ ; copy what should be judged into profiles/.
 set -eo pipefail
@@ -18,8 +19,8 @@ one_workload () {   # name  workload-key  steps  extra bench args...
     local NAME=$1 WL=$2 STEPS=$3; shift 3
     local T=$OUT/${TAG}_${NAME}_tiles.txt
     rm -f $T
-    python3 bench.py --steps $STEPS --warmup 10 --tune-cache $T --profile-csv $OUT/${TAG}_${NAME}_conv_launches_hip_events.csv "$@" \
-        > $OUT/${TAG}_${NAME}_bench_line.json 2> $OUT/${NAME}_bench.err
+    # autotune once; every later pass replays this tile table
+    python3 bench.py --steps 20 --warmup 10 --tune-cache $T --no-cpu-baseline --no-secondary "$@" > /dev/null 2> $OUT/${NAME}_tune.err
     rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -o bench -- \
         python3 bench.py --steps 40 --warmup 5 --tune-cache $T --no-cpu-baseline --no-secondary "$@" > $OUT/stats.log 2>&1
     python3 tools/step_breakdown.py $OUT/stats/bench_kernel_trace.csv > $OUT/${TAG}_${NAME}_step_breakdown.txt
@@ -32,6 +33,10 @@ one_workload () {   # name  workload-key  steps  extra bench args...
     python3 tools/pmc_traffic.py $OUT/pmc_fetch/fetch_counter_collection.csv $OUT/pmc_write/write_counter_collection.csv \
         $OUT/${TAG}_pmc_traffic_${WL}.json $WL > $OUT/${TAG}_pmc_traffic_${WL}.txt
     rm -rf $OUT/pmc_fetch $OUT/pmc_write $OUT/*.log
+    # the bench line last: it reads the traffic file measured above (same kernel sources, same tile table) from profiles/
+    cp $OUT/${TAG}_pmc_traffic_${WL}.json profiles/
+    python3 bench.py --steps $STEPS --warmup 10 --tune-cache $T --profile-csv $OUT/${TAG}_${NAME}_conv_launches_hip_events.csv "$@" \
+        > $OUT/${TAG}_${NAME}_bench_line.json 2> $OUT/${NAME}_bench.err
     echo "== $NAME"; cut -c1-260 $OUT/${TAG}_${NAME}_bench_line.json; head -3 $OUT/${TAG}_${NAME}_step_breakdown.txt
 }
 
