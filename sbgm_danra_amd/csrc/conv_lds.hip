@@ -94,42 +94,56 @@ __global__ __launch_bounds__(256) void conv3x3_lds_kernel(const ConvParams p) {
     constexpr int LPT = (LQ + 255) / 256;       // IN == 2: low-res quads per thread per stage
     const int hl = p.H >> 1, wlo = p.W >> 1;    // IN == 2: low-res extent
     f32x4 rw[WPT], rp[IN == 2 ? LPT : PPT], rs[IN == 2 ? LPT : 1], sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
+    // Loop-invariant parts of the stage addresses, computed once and explicitly (a stage then costs one add per load).
+    // Weight slab: 256 is a multiple of the NCO*4 quads of a tap, so thread tid's u-th quad is tap u*RW + tl, row quad `rem`;
+    // the u-dependent part of its offset is wavefront-uniform (scalar ALU), the per-thread part is one register.
+    constexpr uint32_t OOB = 0x80000000u;       // any offset >= 2^31 fails the buffer bounds check and reads 0 (stays so after + cb*64)
+    constexpr int RW = 256 / (NCO * 4);
+    const int tl = tid / (NCO * 4), rem = tid - tl * (NCO * 4);
+    const uint32_t wlane = (uint32_t)((WINO ? tl * p.Cout : tl * CB * p.Cout) * 16 + rem * 4) * 4u;
+    const uint32_t wlane_last = (WPT - 1) * RW + tl < NTAP ? wlane : OOB;          // the slab may end inside the last 256-quad round
+    uint32_t poff[IN == 2 ? LPT : PPT];
+    if (IN != 2) {
+#pragma unroll
+        for (int u = 0; u < PPT; ++u) {
+            const int q = tid + 256 * u;
+            const int quad = q & 3, pix = q >> 2;
+            const int py = pix / PWID, px = pix - py * PWID;
+            const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+            const bool ok = (q < PQ) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+            poff[u] = ok ? (uint32_t)(((b * p.H + iy) * p.W + ix) * p.Cs + quad * 4) * 4u : OOB;
+        }
+    } else {
+#pragma unroll
+        for (int u = 0; u < LPT; ++u) {                      // low-res pixel (row r, col c) of the L region, edge-clamped
+            const int q = tid + 256 * u;
+            const int quad = q & 3, pix = q >> 2;
+            const int r = pix / LW, c = pix - r * LW;
+            const int ly = min(max((y0 >> 1) - 1 + r, 0), hl - 1), lx = min(max((x0 >> 1) - 1 + c, 0), wlo - 1);
+            poff[u] = q < LQ ? (uint32_t)(((b * hl + ly) * wlo + lx) * p.Cs + quad * 4) * 4u : OOB;
+        }
+    }
+    const float* const aff0 = IN != 0 && p.in_affine != nullptr ? p.in_affine + (((size_t)b * (p.Cs >> 2) + (tid & 3)) * 2) * 4 : nullptr;
+    const __amdgpu_buffer_rsrc_t skr = make_rsrc(IN == 2 && p.in_skip != nullptr ? p.in_skip : p.x, p.x_bytes);
     auto stage_load = [&](int cb) {
 #pragma unroll
         for (int u = 0; u < WPT; ++u) {
-            const int q = tid + 256 * u;
-            const int tap = q / (NCO * 4), rem = q - tap * (NCO * 4);
-            uint32_t off;
-            if (!WINO) off = (uint32_t)(((tap * CB + cb) * p.Cout + co0) * 16 + rem * 4) * 4u;                       // [tap][cb][Cout][16]
-            else off = (uint32_t)(((((tap >> 2) * CB + cb) * 4 + (tap & 3)) * p.Cout + co0) * 16 + rem * 4) * 4u;   // [kh][cb][xi][Cout][16]
-            rw[u] = buf_load4(wr, q < WQ ? off : 0x80000000u);
+            const int t0 = u * RW;                           // tap of this round for tl = 0
+            uint32_t su;                                     // wavefront-uniform
+            if (!WINO) su = (uint32_t)(((t0 * CB + cb) * p.Cout + co0) * 16) * 4u;                                   // [tap][cb][Cout][16]
+            else su = (uint32_t)(((((t0 >> 2) * CB + cb) * 4 + (t0 & 3)) * p.Cout + co0) * 16) * 4u;               // [kh][cb][xi][Cout][16]
+            rw[u] = buf_load4(wr, (u == WPT - 1 ? wlane_last : wlane) + su);
         }
         if (IN != 0 && p.in_affine != nullptr) {             // a thread's quads all share (tid & 3): one scale / shift pair per stage
-            const float* ap = p.in_affine + (((size_t)b * (p.Cs >> 2) + cb * 4 + (tid & 3)) * 2) * 4;
+            const float* ap = aff0 + cb * 32;
             sc = *reinterpret_cast<const f32x4*>(ap);
             sh = *reinterpret_cast<const f32x4*>(ap + 4);
         }
-        if (IN != 2) {
+        const uint32_t cbo = (uint32_t)cb * 64u;
 #pragma unroll
-            for (int u = 0; u < PPT; ++u) {
-                const int q = tid + 256 * u;
-                const int quad = q & 3, pix = q >> 2;
-                const int py = pix / PWID, px = pix - py * PWID;
-                const int iy = y0 - 1 + py, ix = x0 - 1 + px;
-                const bool ok = (q < PQ) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
-                rp[u] = buf_load4(xr, ok ? (uint32_t)(((b * p.H + iy) * p.W + ix) * p.Cs + cb * 16 + quad * 4) * 4u : 0x80000000u);
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < LPT; ++u) {                  // low-res pixel (row r, col c) of the L region, edge-clamped
-                const int q = tid + 256 * u;
-                const int quad = q & 3, pix = q >> 2;
-                const int r = pix / LW, c = pix - r * LW;
-                const int ly = min(max((y0 >> 1) - 1 + r, 0), hl - 1), lx = min(max((x0 >> 1) - 1 + c, 0), wlo - 1);
-                const uint32_t off = q < LQ ? (uint32_t)(((b * hl + ly) * wlo + lx) * p.Cs + cb * 16 + quad * 4) * 4u : 0x80000000u;
-                rp[u] = buf_load4(xr, off);
-                if (p.in_skip != nullptr) rs[u] = buf_load4(make_rsrc(p.in_skip, p.x_bytes), off);
-            }
+        for (int u = 0; u < (IN == 2 ? LPT : PPT); ++u) {
+            rp[u] = buf_load4(xr, poff[u] + cbo);
+            if (IN == 2 && p.in_skip != nullptr) rs[u] = buf_load4(skr, poff[u] + cbo);
         }
     };
     f32x4* const wl0 = wl;
