@@ -191,18 +191,25 @@ typedef struct sbgm_conv_args {
     const float* in_affine;  /* [B][c_pad/4][2][4] scale quad, shift quad; required for mode 1, optional for mode 2 */
     const float* in_skip;    /* mode 2: [B,H/2,W/2,c_pad] or NULL */
     int in_act;              /* mode 2: SBGM_NONE / RELU / SILU / GELU applied to the low-resolution value */
+    /* Optional second weight image in the Winograd layout (sbgm_conv_wino_pack_weight / a sbgm_pack_desc with transposed bit 1).
+     * When given: sbgm_conv2d_tune also times the Winograd candidates, and sbgm_conv2d_fwd takes its weights from here when
+     * winograd bit 0 is set (w_packed stays the implicit-GEMM image for every other kernel).  NULL: as before, a call with
+     * winograd bit 0 reads the Winograd image from w_packed. */
+    const float* w_wino;
 } sbgm_conv_args;
 int sbgm_conv2d_fwd(const sbgm_conv_args* a, void* stream);
 /* Times the kernel / tile / split candidates for exactly this call (same operands; launches are idempotent; synchronises)
  * and writes the fastest as tile[6] = {tile_co, tile_px, splits, waves_per_tile, winograd bit 0, LDS kernel: 0 off / 1 on (bit 1) / 2 double-buffered (bits 1+2)}, the values
- * to put into sbgm_conv_args.  Winograd candidates are skipped (they need the transformed weights); split-K candidates are
- * considered when a->ws is given.  Used by the training path, whose convolutions run op by op. */
+ * to put into sbgm_conv_args.  Winograd candidates are timed when a->w_wino is given (they need the transformed weights);
+ * split-K candidates are considered when a->ws is given.  Used by the training path, whose convolutions run op by op. */
 int sbgm_conv2d_tune(const sbgm_conv_args* a, int* tile, void* stream);
 /* Pack many convolution weights in one launch.  desc: DEVICE array of n descriptors; block_begin = exclusive prefix of
  * sbgm_conv_pack_weights_batched_blocks(Cout, KH, KW, cs) over the descriptors (the workgroups each weight needs),
  * total_blocks = its total; nsteps = sbgm_conv_packed_numel / (Cout*16).
- * transposed != 0 packs the data-gradient operator: then Cout/Cin are the TRANSPOSED sizes (Cout = forward Cin, Cin = forward
- * Cout) and cs is the padded forward Cout, exactly as sbgm_conv_pack_weight_dgrad does for one weight. */
+ * transposed bit 0 packs the data-gradient operator: then Cout/Cin are the TRANSPOSED sizes (Cout = forward Cin, Cin = forward
+ * Cout) and cs is the padded forward Cout, exactly as sbgm_conv_pack_weight_dgrad does for one weight.
+ * transposed bit 1 (3x3 kernels, cs %% 16 == 0, Cout %% 16 == 0): dst is the Winograd image U[kh][cs/16][xi][Cout][16] of
+ * sbgm_conv_wino_pack_weight (sbgm_conv_wino_packed_numel floats) of that operator instead; nsteps is ignored. */
 typedef struct sbgm_pack_desc {
     const float* src;      /* OIHW */
     float* dst;            /* packed [nsteps][Cout][16] */

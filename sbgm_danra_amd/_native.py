@@ -59,7 +59,7 @@ class ConvArgs(C.Structure):
                 ("residual", _vp), ("B", _i), ("H", _i), ("W", _i), ("c_pad", _i), ("Cout", _i), ("KH", _i), ("KW", _i),
                 ("stride", _i), ("pad", _i), ("act", _i), ("tbias_after_act", _i), ("tile_co", _i), ("tile_px", _i),
                 ("splits", _i), ("waves_per_tile", _i), ("winograd", _i), ("in_dil", _i), ("out_h", _i), ("out_w", _i), ("ws", _vp),
-                ("ws_floats", _i64), ("in_mode", _i), ("in_affine", _vp), ("in_skip", _vp), ("in_act", _i)]
+                ("ws_floats", _i64), ("in_mode", _i), ("in_affine", _vp), ("in_skip", _vp), ("in_act", _i), ("w_wino", _vp)]
 
 
 # name -> (restype, argtypes); every symbol include/sbgm_hip.h declares
@@ -154,7 +154,7 @@ SIGNATURES = {
     "sbgm_randn_scaled": (_i, [_vp, _f, _u64, _u64, _i64, _vp]),
 }
 
-ABI_VERSION = 2          # include/sbgm_hip.h: sbgm_abi_version()
+ABI_VERSION = 3          # include/sbgm_hip.h: sbgm_abi_version()
 
 _lib = None
 

@@ -44,6 +44,7 @@ int sbgm_conv2d_fwd(const sbgm_conv_args* a, void* stream) {
     p.in_dil = a->in_dil; p.out_h = a->out_h; p.out_w = a->out_w;
     p.in_mode = a->in_mode; p.in_affine = a->in_affine; p.in_skip = a->in_skip; p.in_act = a->in_act;
     SBGM_CHECK(a->in_mode == 0 || (a->winograd & 3) == 3, "conv2d: in_mode %d needs the LDS-staged Winograd kernel (winograd bits 0 and 1)", a->in_mode);
+    if ((a->winograd & 1) && a->w_wino) p.wp = a->w_wino;
     ConvTile t{a->tile_co ? a->tile_co : (a->Cout % 64 == 0 ? 4 : 2), a->tile_px ? a->tile_px : 2, a->splits ? a->splits : 1,
                a->waves_per_tile ? a->waves_per_tile : 1, a->winograd & 1, (a->winograd & 2) ? ((a->winograd & 4) ? 2 : 1) : 0};
     if (a->winograd & 2) {
@@ -67,8 +68,8 @@ int sbgm_conv2d_fwd(const sbgm_conv_args* a, void* stream) {
 
 int sbgm_conv_pack_weights_batched_blocks(int Cout, int KH, int KW, int c_pad) { return sbgm_conv_pack_blocks(Cout, KH, KW, c_pad); }
 int sbgm_conv_pack_weights_batched(const sbgm_pack_desc* desc_dev, int n, int total_blocks, void* stream) {
-    return sbgm_launch_pack_conv_weights_batched(desc_dev, n, total_blocks, ST);
-}
+    return sbgm_launch_pack_conv_weights_batched(desc_dev, n, total_blocks, ST);   // descriptors live on the device: the caller
+}                                                                                    // guarantees bit 1 only on 3x3, cs%16, Cout%16
 int sbgm_adam_step_blocks(int64_t numel) { return sbgm_adam_blocks(numel); }
 int sbgm_adam_step_batched(const sbgm_adam_desc* desc_dev, int n, int total_blocks, const float* step, float lr, float beta1,
                            float beta2, float eps, float weight_decay, int decoupled, void* stream) {
@@ -141,6 +142,7 @@ int sbgm_conv2d_tune(const sbgm_conv_args* a, int* tile, void* stream) {
     p.res = a->residual; p.B = a->B; p.H = a->H; p.W = a->W; p.Cs = a->c_pad; p.Cout = a->Cout;
     p.act = a->act; p.tbias_after_act = a->tbias_after_act;
     p.in_dil = a->in_dil; p.out_h = a->out_h; p.out_w = a->out_w;
+    p.wp_wino = a->w_wino;
     ConvTile best{a->Cout % 64 == 0 ? 4 : 2, 2, 1, 1, 0, 0};
     if (sbgm_tune_conv(ConvGeom{a->KH, a->KW, a->stride, a->pad}, p, a->ws, a->ws ? (size_t)a->ws_floats : 0, ST, &best)) return 1;
     tile[0] = best.fco; tile[1] = best.fpx; tile[2] = best.splits; tile[3] = best.ws; tile[4] = best.wino; tile[5] = best.lds;

@@ -330,7 +330,9 @@ __global__ __launch_bounds__(256) void pack_conv_weights_batched_kernel(const sb
         const int mid = (lo + hi + 1) >> 1;
         if (desc[mid].block_begin <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
     }
-    const sbgm_pack_desc d = desc[lo];
+    sbgm_pack_desc d = desc[lo];
+    const bool wino = (d.transposed & 2) != 0;               // validated on the host: 3x3, tiled
+    d.transposed &= 1;
     const int rel = blockIdx.x - d.block_begin;
     if (!pack_tiled(d.Cout, d.cs, d.KH * d.KW)) {
         const size_t total = (size_t)d.nsteps * d.Cout * 16;
@@ -352,6 +354,20 @@ __global__ __launch_bounds__(256) void pack_conv_weights_batched_kernel(const sb
     }
     __syncthreads();
     const int k16 = threadIdx.x & 15, col = threadIdx.x >> 4;   // destination: c = c0 + k16, co = co0 + col
+    if (wino) {                                              // U[kh][cb][xi][Cout][16], U = G g along the filter row (conv_wino.hip)
+        for (int kh = 0; kh < 3; ++kh) {
+            float g[3];
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int tap = kh * 3 + kw;
+                g[kw] = d.transposed ? pk[k16 * RS + col * Tp + (T - 1 - tap)] : pk[col * RS + k16 * Tp + tap];
+            }
+            const float u[4] = {g[0], 0.5f * ((g[0] + g[1]) + g[2]), 0.5f * ((g[0] - g[1]) + g[2]), g[2]};
+#pragma unroll
+            for (int xi = 0; xi < 4; ++xi) d.dst[((size_t)((kh * cbs + cb) * 4 + xi) * d.Cout + co0) * 16 + threadIdx.x] = u[xi];
+        }
+        return;
+    }
     for (int tap = 0; tap < T; ++tap) {
         const float v = d.transposed ? pk[k16 * RS + col * Tp + (T - 1 - tap)] : pk[col * RS + k16 * Tp + tap];
         d.dst[((size_t)(tap * cbs + cb) * d.Cout + co0) * 16 + threadIdx.x] = v;

@@ -979,7 +979,7 @@ const char* sbgm_get_error();
 extern "C" {
 
 const char* sbgm_last_error(void) { return sbgm_get_error(); }
-int sbgm_abi_version(void) { return 2; }
+int sbgm_abi_version(void) { return 3; }
 int sbgm_model_config_size(void) { return (int)sizeof(sbgm_model_config); }
 
 int sbgm_model_create(const sbgm_model_config* cfg, sbgm_model** out) {

@@ -241,41 +241,62 @@ class _PackPlan:
     def __init__(self):
         self.entries = {}          # (data_ptr, cs) -> dict(w_shape, cs, dgrad, fwd=tensor, bwd=tensor|None)
         self.desc = None           # device descriptor table
+        self.keep = []             # superseded tables (still referenced by captured steps)
+        self.dirty = False         # entries / layouts were added since the table was built
         self.sig = None
         self.blocks = 0
         self.fresh = False
         self.owner = lambda: None
 
-    def note(self, w, cs, dgrad):
+    def note(self, w, cs, dgrad, layout):
+        """layout 'g' / 'w': the tuned forward kernel of this call read the implicit-GEMM / the Winograd weight image.  One weight
+        may be needed in both (two batch shapes whose tuned tiles differ): every layout ever used is packed from then on."""
         key = (w.data_ptr(), cs)
         e = self.entries.get(key)
         if e is None:
             base = w._base if w._base is not None else w
-            self.entries[key] = dict(shape=tuple(w.shape), cs=cs, dgrad=dgrad, fwd=None, bwd=None, ref=weakref.ref(base))
-            self.desc = None
-        elif dgrad and not e["dgrad"]:
+            e = self.entries[key] = dict(shape=tuple(w.shape), cs=cs, dgrad=False, ref=weakref.ref(base), need=set(),
+                                         img={("fwd", "g"): None, ("fwd", "w"): None, ("bwd", "g"): None, ("bwd", "w"): None})
+            self.dirty = True
+        if dgrad and not e["dgrad"]:
             e["dgrad"] = True
-            self.desc = None
+            self.dirty = True
+        if ("fwd", layout) not in e["need"]:
+            e["need"].add(("fwd", layout))
+            self.dirty = True
+
+    def note_bwd(self, w, cs, layout):
+        e = self.entries.get((w.data_ptr(), cs))
+        if e is not None and ("bwd", layout) not in e["need"]:
+            e["need"].add(("bwd", layout))
+            e["dgrad"] = True
+            self.dirty = True
 
     def lookup(self, w, cs):
         e = self.entries.get((w.data_ptr(), cs)) if self.fresh else None
-        return e if e is not None and e["fwd"] is not None and e["shape"] == tuple(w.shape) else None
+        return e if e is not None and e.get("packed") and e["shape"] == tuple(w.shape) else None
 
     def build(self, dev):
         descs, blk = [], 0
         for (ptr, cs), e in self.entries.items():
             cout, cin, k, _ = e["shape"]
-            e["fwd"] = torch.empty(_L().sbgm_conv_packed_numel(cout, k, k, cs), device=dev)
-            jobs = [(e["fwd"], cout, cin, cs, 0)]
-            if e["dgrad"]:
-                e["bwd"] = torch.empty(_L().sbgm_conv_packed_numel(cin, k, k, cout), device=dev)
-                jobs.append((e["bwd"], cin, cout, (cout + 15) // 16 * 16, 1))
+            cso = (cout + 15) // 16 * 16
+            jobs = []
+            for (role, layout) in sorted(e["need"]):
+                co_, ci_, cs_ = (cout, cin, cs) if role == "fwd" else (cin, cout, cso)
+                n = _L().sbgm_conv_wino_packed_numel(co_, cs_) if layout == "w" else _L().sbgm_conv_packed_numel(co_, k, k, cs_)
+                if e["img"][(role, layout)] is None:         # never re-allocated: a captured step keeps reading the image it saw
+                    e["img"][(role, layout)] = torch.empty(n, device=dev)
+                jobs.append((e["img"][(role, layout)], co_, ci_, cs_, (1 if role == "bwd" else 0) | (2 if layout == "w" else 0)))
+            e["packed"] = True
             for dst, co_, ci_, cs_, tr in jobs:
                 nsteps = dst.numel() // (co_ * 16)
                 descs.append(N.PackDesc(ptr, dst.data_ptr(), co_, ci_, k, k, cs_, nsteps, tr, blk))
                 blk += _L().sbgm_conv_pack_weights_batched_blocks(co_, k, k, cs_)
         raw = (N.PackDesc * len(descs))(*descs)
         host = torch.frombuffer(bytearray(bytes(raw)), dtype=torch.uint8)
+        if self.desc is not None:
+            self.keep.append(self.desc)                      # an earlier capture replays its pack launch from this table
         self.desc, self.n, self.blocks = host.to(dev), len(descs), blk
 
     def run(self, dev):
@@ -286,35 +307,71 @@ class _PackPlan:
         if stale and not torch.cuda.is_current_stream_capturing():
             for k in stale:
                 del self.entries[k]
-            self.desc = None
-        if not self.entries or torch.cuda.is_current_stream_capturing() and self.desc is None:
+            self.dirty = True
+        capturing = torch.cuda.is_current_stream_capturing()
+        if not self.entries or capturing and self.desc is None:
             return
-        if self.desc is None:
+        if (self.desc is None or self.dirty) and not capturing:      # (a capture replays the table it was recorded with)
             self.build(dev)
+            self.dirty = False
         N.check(_L().sbgm_conv_pack_weights_batched(self.desc.data_ptr(), self.n, self.blocks, _st()))
         self.fresh = True
 
 
 _PLANS = {}            # id(net) -> _PackPlan
 _ACTIVE_PLAN = [None]
+_USE_WINO = [True]     # debugging switch: False = the training convolutions never use the Winograd kernels
 
 
-def _conv_launch(x, packed, out, cs, cout, k, stride, pad, bias=None, res=None, tbias=None, in_dil=0, out_hw=(0, 0)):
+def _wino_ok(k, stride, pad, in_dil, cs, cout, W):
+    """geometries the Winograd F(2,3) kernels take (3x3 / stride 1 / pad 1, channels in 16s, even width)"""
+    return k == 3 and stride == 1 and pad == 1 and not in_dil and cs % 16 == 0 and cout % 32 == 0 and W % 2 == 0
+
+
+class _MissingImage(Exception):
+    """the geometry's tuned tile reads a weight image ('g' implicit GEMM / 'w' Winograd) the caller did not bring"""
+
+
+def _conv_launch(x, packed, out, cs, cout, k, stride, pad, bias=None, res=None, tbias=None, in_dil=0, out_hw=(0, 0), wino=None,
+                 on_missing="default"):
     """One convolution through the per-op C ABI.  The first time a geometry is seen (outside graph capture) the library
-    times its kernel / tile / split-K candidates on these very operands and the winner is reused from then on."""
+    times its kernel / tile / split-K candidates on these very operands and the winner is reused from then on.
+    packed / wino: the implicit-GEMM and the Winograd weight image; either may be None when the geometry's tile is known to read
+    the other.  Returns True when the launch read the Winograd image."""
     B, H, W, _ = x.shape
-    key = (B, H, W, cs, cout, k, stride, pad, in_dil, out_hw, bias is not None, res is not None, tbias is not None)
+    # the key says whether Winograd candidates take part for this geometry: first-step calls then bring both images, so the
+    # cached tile never depends on which caller tuned it
+    wk = _USE_WINO[0] and _wino_ok(k, stride, pad, in_dil, cs, cout, W)
+    key = (B, H, W, cs, cout, k, stride, pad, in_dil, out_hw, bias is not None, res is not None, tbias is not None, wk)
     ws = _splitk_ws(x.device)
-    a = N.ConvArgs(x.data_ptr(), packed.data_ptr(), out.data_ptr(), None, N.ptr(bias), N.ptr(tbias), N.ptr(res), B, H, W, cs, cout, k, k,
-                   stride, pad, N.NONE, 0, 0, 0, 0, 0, 0, in_dil, out_hw[0], out_hw[1], ws.data_ptr(), _SPLITK_FLOATS)
+    a = N.ConvArgs(x.data_ptr(), (packed if packed is not None else wino).data_ptr(), out.data_ptr(), None, N.ptr(bias), N.ptr(tbias),
+                   N.ptr(res), B, H, W, cs, cout, k, k, stride, pad, N.NONE, 0, 0, 0, 0, 0, 0, in_dil, out_hw[0], out_hw[1],
+                   ws.data_ptr(), _SPLITK_FLOATS, 0, None, None, 0, N.ptr(wino) if wk else None)
     tile = _TILES.get(key)
-    if tile is None and cout % 32 == 0 and not torch.cuda.is_current_stream_capturing():
+    if tile is None and cout % 32 == 0 and not torch.cuda.is_current_stream_capturing() and packed is not None and (wino is not None or not wk):
         t6 = (C.c_int * 6)()
         N.check(_L().sbgm_conv2d_tune(C.byref(a), t6, _st()))
         tile = _TILES[key] = (t6[0], t6[1], t6[2], t6[3], t6[4] | (2 if t6[5] else 0) | (4 if t6[5] == 2 else 0))
+    if tile is not None and (tile[4] & 1) and wino is None and on_missing == "raise":
+        raise _MissingImage("w")
+    if tile is not None and ((tile[4] & 1) and wino is None or not (tile[4] & 1) and packed is None):
+        tile = None                                    # the tuned choice reads an image this call does not have: default tile
     if tile is not None:
         a.tile_co, a.tile_px, a.splits, a.waves_per_tile, a.winograd = tile
+    elif packed is None:
+        raise _MissingImage("g")
     N.check(_L().sbgm_conv2d_fwd(C.byref(a), _st()))
+    return bool(a.winograd & 1)
+
+
+def _pack_single(w, cout, cin, k, cs, flags):
+    """one weight through the batched pack entry (flags: bit 0 data-gradient operator, bit 1 Winograd image); first step only"""
+    wino = bool(flags & 2)
+    dst = torch.empty(_L().sbgm_conv_wino_packed_numel(cout, cs) if wino else _L().sbgm_conv_packed_numel(cout, k, k, cs), device=w.device)
+    d = N.PackDesc(w.data_ptr(), dst.data_ptr(), cout, cin, k, k, cs, dst.numel() // (cout * 16), flags, 0)
+    dev = torch.frombuffer(bytearray(bytes(d)), dtype=torch.uint8).to(w.device)
+    N.check(_L().sbgm_conv_pack_weights_batched(dev.data_ptr(), 1, _L().sbgm_conv_pack_weights_batched_blocks(cout, k, k, cs), _st()))
+    return dst
 
 
 class ConvFn(torch.autograd.Function):
@@ -327,21 +384,30 @@ class ConvFn(torch.autograd.Function):
         cout, cin, k, _ = w.shape
         plan = _ACTIVE_PLAN[0]
         e = plan.lookup(w, cs) if plan is not None else None
-        if e is not None:
-            packed = e["fwd"]
-        else:
+        oh, ow = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        y = torch.empty(B, oh, ow, cout, device=x.device)
+        used = None
+        if e is not None:                                    # packed by the step's batched launch, in the layout(s) its tiles read
+            try:
+                used = _conv_launch(x, e["img"][("fwd", "g")], y, cs, cout, k, stride, pad, bias, res, tbias, wino=e["img"][("fwd", "w")],
+                                    on_missing="raise")
+            except _MissingImage:                            # another batch shape of the same weight wants the other layout
+                used = None
+        if used is None:
             packed = torch.empty(_L().sbgm_conv_packed_numel(cout, k, k, cs), device=x.device)
             N.check(_L().sbgm_conv_pack_weight(w.data_ptr(), packed.data_ptr(), cout, cin, k, k, cs, _st()))
+            pw = None
+            if _USE_WINO[0] and _wino_ok(k, stride, pad, 0, cs, cout, W) and not torch.cuda.is_current_stream_capturing():
+                pw = _pack_single(w, cout, cin, k, cs, 2)
+            used = _conv_launch(x, packed, y, cs, cout, k, stride, pad, bias, res, tbias, wino=pw)
             base = w._base if w._base is not None else w
             if plan is not None and base.is_leaf and base.data_ptr() == w.data_ptr() and base.numel() == w.numel():
                 # a parameter or a reshaped view of one (nn.Linear weights), not a derived tensor: batch-pack it from the next step on
-                plan.note(w, cs, dgrad=x.requires_grad and cs == cin and cs % 32 == 0)
-        oh, ow = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
-        y = torch.empty(B, oh, ow, cout, device=x.device)
-        _conv_launch(x, packed, y, cs, cout, k, stride, pad, bias, res, tbias)
+                plan.note(w, cs, dgrad=x.requires_grad and cs == cin and cs % 32 == 0, layout="w" if used else "g")
         ctx.save_for_backward(x, w, bias)
         ctx.geom = (stride, pad, bias is not None, res is not None, tbias is not None)
-        ctx.packed_bwd = e["bwd"] if e is not None else None
+        ctx.packed_bwd = (e["img"][("bwd", "g")], e["img"][("bwd", "w")]) if e is not None else None
+        ctx.plan = plan
         ctx.arena = _ACTIVE_ARENA[0]
         return y
 
@@ -369,12 +435,25 @@ class ConvFn(torch.autograd.Function):
         elif ctx.needs_input_grad[0]:
             if cs != cin or cs % 32:
                 raise NotImplementedError("data gradient w.r.t. a channel-padded input is not needed on this path")
-            packed = ctx.packed_bwd
-            if packed is None:
+            dx = torch.empty_like(x)
+            dil = 2 if stride == 2 else 0
+            used = None
+            if ctx.packed_bwd is not None and (ctx.packed_bwd[0] is not None or ctx.packed_bwd[1] is not None):
+                try:
+                    used = _conv_launch(dy, ctx.packed_bwd[0], dx, cout, cin, k, 1, k - 1 - pad, in_dil=dil, out_hw=(H, W),
+                                        wino=ctx.packed_bwd[1], on_missing="raise")
+                except _MissingImage:
+                    used = None
+            if used is None:
                 packed = torch.empty(_L().sbgm_conv_packed_numel(cin, k, k, cout), device=x.device)
                 N.check(_L().sbgm_conv_pack_weight_dgrad(w.data_ptr(), packed.data_ptr(), cout, cin, k, k, _st()))
-            dx = torch.empty_like(x)
-            _conv_launch(dy, packed, dx, cout, cin, k, 1, k - 1 - pad, in_dil=2 if stride == 2 else 0, out_hw=(H, W))
+                pw = None
+                if _USE_WINO[0] and _wino_ok(k, 1, k - 1 - pad, dil, cout, cin, dy.shape[2]) and cout % 16 == 0 \
+                        and not torch.cuda.is_current_stream_capturing():
+                    pw = _pack_single(w, cin, cout, k, cout, 3)
+                used = _conv_launch(dy, packed, dx, cout, cin, k, 1, k - 1 - pad, in_dil=dil, out_hw=(H, W), wino=pw)
+                if ctx.plan is not None:
+                    ctx.plan.note_bwd(w, cs, "w" if used else "g")
         want_db = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             if _WGRAD_LOG[0] is not None:

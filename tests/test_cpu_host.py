@@ -101,7 +101,7 @@ def test_library_exports_every_declared_symbol():
     assert len(declared) >= 35
     assert declared == set(N.SIGNATURES), declared ^ set(N.SIGNATURES)
     lib = N.lib()                                # dlopen + resolve all of them (no compute, no GPU needed)
-    assert lib.sbgm_abi_version() == 2
+    assert lib.sbgm_abi_version() == 3
     raw = ctypes.CDLL(N.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name

@@ -458,3 +458,35 @@ def test_batched_weight_pack_equals_single_packs(transposed):
     assert len(outs) >= 4
     for single, batched in outs:
         assert torch.equal(single, batched)
+
+
+@pytest.mark.parametrize("transposed", [0, 1])
+def test_batched_weight_pack_winograd_layout(transposed):
+    """sbgm_pack_desc.transposed bit 1: the Winograd image of the forward operator == sbgm_conv_wino_pack_weight; of the
+    data-gradient operator == sbgm_conv_wino_pack_weight of the explicitly transposed + 180-degree-flipped weight; and a
+    convolution through it (the training path's use) matches F.conv2d / its input gradient"""
+    shapes = [(64, 64), (128, 64), (64, 48), (32, 128)]                                          # (Cout, Cin), 3x3
+    ws = [rnd(co, ci, 3, 3, seed=i, scale=0.1).to(DEV) for i, (co, ci) in enumerate(shapes)]
+    descs, outs, blk, keep = [], [], 0, []
+    for w, (co, ci) in zip(ws, shapes):
+        if transposed:
+            if ci % 16 or co % 16:
+                continue
+            weff = w.permute(1, 0, 2, 3).flip(2, 3).contiguous()                                   # the dgrad operator's OIHW weight
+            pco, pci, cs = ci, co, co
+        else:
+            weff, pco, pci, cs = w, co, ci, (ci + 15) // 16 * 16
+        numel = lib().sbgm_conv_wino_packed_numel(pco, cs)
+        single, batched = torch.empty(numel, device=DEV), torch.full((numel,), 7.0, device=DEV)
+        N.check(lib().sbgm_conv_wino_pack_weight(weff.data_ptr(), single.data_ptr(), pco, pci, cs, N.stream()))
+        descs.append(N.PackDesc(w.data_ptr(), batched.data_ptr(), pco, pci, 3, 3, cs, 0, transposed | 2, blk))
+        blk += lib().sbgm_conv_pack_weights_batched_blocks(pco, 3, 3, cs)
+        outs.append((single, batched))
+        keep.append(weff)
+    raw = (N.PackDesc * len(descs))(*descs)
+    dev = torch.frombuffer(bytearray(bytes(raw)), dtype=torch.uint8).to(DEV)
+    N.check(lib().sbgm_conv_pack_weights_batched(dev.data_ptr(), len(descs), blk, N.stream()))
+    torch.cuda.synchronize()
+    assert len(outs) >= 3
+    for single, batched in outs:
+        assert torch.equal(single, batched)
