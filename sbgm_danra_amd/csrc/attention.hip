@@ -176,19 +176,34 @@ __global__ __launch_bounds__(256) void mha_core_lds_kernel(const float* __restri
             qf[n][j] *= scale;
         }
     }
-    const int uq = 4 * D16;                                   // quads per (zero-padded) key row
-    for (int c0 = 0; c0 < S; c0 += MHA_KCH) {
-        __syncthreads();                                      // every wave is done with the previous chunk
-        for (int i = tid; i < MHA_KCH * uq; i += 256) {
+    constexpr int uq = 4 * D16;                               // quads per (zero-padded) key row
+    constexpr int NLD = MHA_KCH * uq / 256;                   // K (and V) quads a thread stages per chunk
+    // register-staged chunks: the global loads of chunk c+1 are issued before the MFMAs of chunk c and land while the matrix
+    // pipe works (a workgroup is alone on its CU at the usual grid sizes, so nothing else would hide that latency)
+    f32x4 rk[NLD], rv[NLD];
+    auto chunk_load = [&](int c0) {
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int i = tid + 256 * u;
             const int key = i / uq, q4 = i - key * uq;
             const bool ok = c0 + key < S && 4 * q4 < d;
             const float* src = base + (size_t)(c0 + key) * row_stride + 4 * q4;
-            const f32x4 kv = ok ? *reinterpret_cast<const f32x4*>(src + C) : f32x4{0.f, 0.f, 0.f, 0.f};
-            const f32x4 vv = ok ? *reinterpret_cast<const f32x4*>(src + 2 * C) : f32x4{0.f, 0.f, 0.f, 0.f};
-            Kl[(key * KU + (q4 >> 2)) * 4 + (((q4 & 3) + (key >> 1)) & 3)] = kv;
-            *reinterpret_cast<f32x4*>(Vl + key * VS + 4 * q4) = vv;
+            rk[u] = ok ? *reinterpret_cast<const f32x4*>(src + C) : f32x4{0.f, 0.f, 0.f, 0.f};
+            rv[u] = ok ? *reinterpret_cast<const f32x4*>(src + 2 * C) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    chunk_load(0);
+    for (int c0 = 0; c0 < S; c0 += MHA_KCH) {
+        __syncthreads();                                      // every wave is done with the previous chunk
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) {
+            const int i = tid + 256 * u;
+            const int key = i / uq, q4 = i - key * uq;
+            Kl[(key * KU + (q4 >> 2)) * 4 + (((q4 & 3) + (key >> 1)) & 3)] = rk[u];
+            *reinterpret_cast<f32x4*>(Vl + key * VS + 4 * q4) = rv[u];
         }
         __syncthreads();
+        if (c0 + MHA_KCH < S) chunk_load(c0 + MHA_KCH);
         const int kend = min(MHA_KCH, S - c0);
         // key blocks outermost, this wave's query blocks innermost: one K / V fragment read serves all of them and their
         // QK^T -> softmax -> PV chains are independent, so the latencies of one hide behind the MFMAs of the others
@@ -265,7 +280,10 @@ int sbgm_launch_mha_core(const float* qkv, float* out, int B, int S, int C, int 
         // query blocks of one (sample, head) are dealt to `qsplit` workgroups: one workgroup per CU if possible (every split stages
         // K / V again, so fewer is better for traffic), at most 16 blocks each
         const int qblocks = (S + 15) / 16, bh = B * heads;
-        int qsplit = std::max((256 + bh - 1) / bh, (qblocks + 4 * MHA_NQ_MAX - 1) / (4 * MHA_NQ_MAX));
+        // one workgroup per CU; two from S = 1024 on, where a workgroup's 8 chunks are long enough for a second one to fill its
+        // staging phases (measured 134 -> 117 us at B=16, S=1024; at S=256 twice the K/V staging costs more than it hides)
+        const int wg_target = S >= 1024 ? 512 : 256;
+        int qsplit = std::max((wg_target + bh - 1) / bh, (qblocks + 4 * MHA_NQ_MAX - 1) / (4 * MHA_NQ_MAX));
         qsplit = std::max(1, std::min(qsplit, qblocks));
         const int per_wave = (qblocks + 4 * qsplit - 1) / (4 * qsplit);          // query blocks per wave
         const int nq = per_wave <= 1 ? 1 : per_wave <= 2 ? 2 : 4;
