@@ -86,8 +86,29 @@ struct sbgm_model {
     static constexpr int PROF_REPS = 4;
     hipStream_t graph_stream = nullptr;     // private capture stream (the caller's may be the legacy default stream)
     hipEvent_t ev_in = nullptr, ev_out = nullptr;
+    // The captured SDE step is kept across sampler calls: capture + instantiation of its ~75 kernel nodes cost ~3 ms, as much as
+    // two steps.  Everything a step bakes in is in the key (shapes, sampler kind, caller tensors, scalar arguments, workspace,
+    // tile-table generation); what changes between runs lives in device memory (step table, step counter, RNG offset AND seed).
+    struct StepGraphKey {
+        int B, H, W, kind, guided, bn_train, domain_w;
+        const void *y, *cond, *lsm, *topo, *origins, *ws, *table;
+        size_t ws_bytes;
+        float cfg, cfg_corr, snr_nn;
+        unsigned long long plan_gen;
+    };
+    StepGraphKey step_key{};
+    hipGraph_t step_graph = nullptr;
+    hipGraphExec_t step_exec = nullptr;
+    unsigned long long plan_gen = 0;         // bumped whenever the tile table changes (the captured launches embed tile choices)
+    void drop_step_graph() {
+        if (step_exec) (void)hipGraphExecDestroy(step_exec);
+        if (step_graph) (void)hipGraphDestroy(step_graph);
+        step_exec = nullptr;
+        step_graph = nullptr;
+    }
 
     ~sbgm_model() {
+        drop_step_graph();
         if (arena) (void)hipFree(arena);
         if (ws) (void)hipFree(ws);
         if (d_state) (void)hipFree(d_state);
@@ -301,6 +322,7 @@ int sbgm_model::build(const sbgm_model_config& c) {
 
 int sbgm_model::ensure_ws(size_t bytes) {
     if (bytes <= ws_bytes) return 0;
+    drop_step_graph();                       // its nodes point into the old workspace
     if (ws) SBGM_HIP(hipFree(ws));
     ws = nullptr; ws_bytes = 0;
     SBGM_HIP(hipMalloc(&ws, bytes));
@@ -479,6 +501,7 @@ int sbgm_model::conv(const ConvGeom& g, ConvParams p, hipStream_t st) {
             ConvTile best_t = pick_tile(g, p);
             if (sbgm_tune_conv(g, p, partial, PARTIAL_FLOATS, st, &best_t)) return 1;
             tuned[key] = best_t;
+            ++plan_gen;
         }
     }
     ConvTile ct = pick_tile(g, p);
@@ -850,12 +873,14 @@ int sbgm_model::sampler(const sbgm_sampler_args& a, hipStream_t caller) {
     if (table_cap < N) {
         if (d_table) SBGM_HIP(hipFree(d_table));
         d_table = nullptr;
-        SBGM_HIP(hipMalloc(&d_table, sizeof(StepScalars) * N));
-        table_cap = N;
+        const int cap = std::max(N, 4096);                   // roomy: a new table address invalidates the cached step graph
+        SBGM_HIP(hipMalloc(&d_table, sizeof(StepScalars) * cap));
+        table_cap = cap;
     }
     SBGM_HIP(hipMemcpyAsync(d_table, tab.data(), sizeof(StepScalars) * N, hipMemcpyHostToDevice, st));
-    SBGM_HIP(hipMemsetAsync(d_state, 0, sizeof(SamplerState), st));
-    SBGM_HIP(hipStreamSynchronize(st));                   // tab is a stack-lifetime host buffer
+    const SamplerState state0{0ull, 0ull, (unsigned long long)a.seed, (unsigned long long)N};
+    SBGM_HIP(hipMemcpyAsync(d_state, &state0, sizeof(SamplerState), hipMemcpyHostToDevice, st));
+    SBGM_HIP(hipStreamSynchronize(st));                   // tab / state0 are stack-lifetime host buffers
 
     // persistent sampler buffers live at the top of the workspace, the forward uses the rest
     // layout (BE = B, or 2B with guidance): x [BE*per] (rows B.. mirror rows 0..B-1), score [BE*per], x_mean [B*per]
@@ -940,24 +965,34 @@ int sbgm_model::sampler(const sbgm_sampler_args& a, hipStream_t caller) {
     ws_bytes = fwd_bytes;            // forward() must not touch the sampler slabs
     int rc = 0;
     if (graphed) {
-        hipGraph_t graph = nullptr;
-        hipGraphExec_t exec = nullptr;
-        hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
-        if (e == hipSuccess) {
-            rc = one_step(false);
-            hipError_t e2 = hipStreamEndCapture(st, &graph);
-            if (rc == 0 && e2 == hipSuccess && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
-                for (int i = 0; i < N && rc == 0; ++i)
-                    if (hipGraphLaunch(exec, st) != hipSuccess) { sbgm_set_error("hipGraphLaunch failed at step %d", i); rc = 2; }
-            } else if (rc == 0) {
-                sbgm_set_error("hipGraph capture/instantiate failed: %s", hipGetErrorString(e2));
+        StepGraphKey key{};                                  // (value-initialised: the padding bytes compare equal)
+        key.B = B; key.H = H; key.W = W; key.kind = a.kind; key.guided = guided; key.bn_train = a.bn_train; key.table = d_table;
+        key.domain_w = a.domain_w; key.y = y_e; key.cond = cond_e; key.lsm = lsm_e; key.topo = topo_e; key.origins = a.tile_origins;
+        key.ws = ws; key.ws_bytes = saved_ws; key.cfg = a.cfg_scale; key.cfg_corr = a.cfg_scale_corrector; key.snr_nn = snr_nn;
+        key.plan_gen = plan_gen;
+        const bool reuse = step_exec != nullptr && !guided && std::memcmp(&key, &step_key, sizeof key) == 0;
+        if (!reuse) {
+            drop_step_graph();
+            hipError_t e = hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal);
+            if (e == hipSuccess) {
+                rc = one_step(false);
+                hipError_t e2 = hipStreamEndCapture(st, &step_graph);
+                if (rc == 0 && (e2 != hipSuccess || hipGraphInstantiate(&step_exec, step_graph, nullptr, nullptr, 0) != hipSuccess)) {
+                    sbgm_set_error("hipGraph capture/instantiate failed: %s", hipGetErrorString(e2));
+                    rc = 2;
+                }
+                if (rc) drop_step_graph();
+                else step_key = key;
+            } else {
+                sbgm_set_error("hipStreamBeginCapture failed: %s", hipGetErrorString(e));
                 rc = 2;
             }
-            if (exec) (void)hipGraphExecDestroy(exec);
-            if (graph) (void)hipGraphDestroy(graph);
-        } else {
-            sbgm_set_error("hipStreamBeginCapture failed: %s", hipGetErrorString(e));
-            rc = 2;
+        }
+        for (int i = 0; i < N && rc == 0; ++i)
+            if (hipGraphLaunch(step_exec, st) != hipSuccess) { sbgm_set_error("hipGraphLaunch failed at step %d", i); rc = 2; }
+        if (guided) {                                        // its condition copies are freed when this call returns
+            (void)hipStreamSynchronize(st);
+            drop_step_graph();
         }
     } else {
         for (int i = 0; i < N && rc == 0; ++i) rc = one_step(z != nullptr);
@@ -1136,6 +1171,7 @@ int sbgm_model_tune_load(sbgm_model* m, const char* path) {
     }
     fclose(f);
     for (auto& kv : table) m->tuned[kv.first] = kv.second;
+    ++m->plan_gen;
     return 0;
 }
 

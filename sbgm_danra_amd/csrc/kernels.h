@@ -179,6 +179,9 @@ struct StepScalars {       // one row of the device-side step table
 struct SamplerState {      // device-resident, lets one captured graph serve every step
     unsigned long long step;        // advanced by the predictor kernel
     unsigned long long rng_offset;  // Philox counter base, advanced by every noise-drawing kernel
+    unsigned long long seed;        // Philox key of the run: read from here when a state is given, so that a captured step is
+                                    // reusable across runs with different seeds (the by-value seed argument serves eager calls)
+    unsigned long long n_steps;     // length of the run (0: use the launch argument): the last step does not advance past it
 };
 // optional map from tile-local quads to domain-global Philox counters (null origins = plain element order)
 struct NoiseMap {

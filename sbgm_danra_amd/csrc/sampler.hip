@@ -34,6 +34,7 @@ __global__ __launch_bounds__(256) void init_noise_kernel(float* __restrict__ x, 
                                                          unsigned long long seed, const SamplerState* __restrict__ state,
                                                          unsigned long long off_val, size_t n4, NoiseMap nm) {
     const unsigned long long off = state ? state->rng_offset : off_val;
+    if (state) seed = state->seed;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         const f32x4 n = z ? reinterpret_cast<const f32x4*>(z)[i] : philox_normal4(seed, off, noise_index(nm, i));
         reinterpret_cast<f32x4*>(x)[i] = n * scale;
@@ -49,6 +50,7 @@ __global__ __launch_bounds__(256) void em_update_kernel(float* __restrict__ x, f
                                                         NoiseMap nm) {
     const StepScalars sc = state ? table[state->step] : sc_val;
     const unsigned long long off = state ? state->rng_offset : off_val;
+    if (state) seed = state->seed;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         const f32x4 xv = reinterpret_cast<const f32x4*>(x)[i];
         const f32x4 sv = reinterpret_cast<const f32x4*>(score)[i];
@@ -63,12 +65,13 @@ __global__ __launch_bounds__(256) void em_update_kernel(float* __restrict__ x, f
 __global__ void advance_kernel(SamplerState* state, const StepScalars* table, float* t_dev, int B, int advance_step,
                                int n_steps) {
     const unsigned long long s = state->step;
+    const unsigned long long ns = state->n_steps ? state->n_steps : (unsigned long long)n_steps;
     const int i = threadIdx.x;
     if (advance_step && t_dev && i < B) t_dev[i] = table[s].t_next;
     __syncthreads();
     if (i == 0) {
         state->rng_offset += 1;
-        if (advance_step) state->step = (s + 1 < (unsigned long long)n_steps) ? s + 1 : s;
+        if (advance_step) state->step = (s + 1 < ns) ? s + 1 : s;
     }
 }
 
@@ -105,6 +108,7 @@ __global__ __launch_bounds__(256) void langevin_kernel(float* __restrict__ x, co
     const bool per_tile = nm.origins != nullptr;
     const size_t per4 = n4 / (size_t)B;
     const unsigned long long off = state ? state->rng_offset : off_val;
+    if (state) seed = state->seed;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         if (per_tile) {
             const float rt = snr_noise_norm / (float)sqrt(sumsq[i / per4]);

@@ -244,6 +244,8 @@ class _Engine:
         N.check(self.lib.sbgm_model_create(C.byref(cfg), C.byref(h)))
         self.h = h
         self.version = None
+        self._fast = None
+        self._mods = None
         self.names = [self.lib.sbgm_model_param_name(self.h, i).decode()
                       for i in range(self.lib.sbgm_model_num_params(self.h))]
 
@@ -254,10 +256,32 @@ class _Engine:
         except Exception:
             pass
 
+    def _fast_version(self, net):
+        """(identity, address, version) of every parameter / buffer over a cached module list: 0.1 ms instead of the 0.75 ms a
+        state_dict() walk costs, paid by every forward / sampler call.  A changed module tree shows up as a mismatch of the full
+        check below, which rebuilds the list."""
+        mods = self._mods
+        if mods is None:
+            mods = self._mods = list(net.modules())
+        out = [N.generation()]
+        for m in mods:
+            for v in m._parameters.values():
+                if v is not None:
+                    out.append((id(v), v.data_ptr(), v._version))
+            for v in m._buffers.values():
+                if v is not None:
+                    out.append((id(v), v.data_ptr(), v._version))
+        return tuple(out)
+
     def upload(self, net: "ScoreNet"):
+        fast = self._fast_version(net)
+        if fast == self._fast:
+            return
+        self._mods = None
         sd = net.state_dict(keep_vars=True)
         ver = (N.generation(),) + tuple((k, v.data_ptr(), v._version) for k, v in sd.items())
         if ver == self.version:
+            self._fast = self._fast_version(net)
             return
         missing = [k for k in self.names if k not in sd]
         extra = [k for k in sd if k not in self.names]
@@ -275,6 +299,7 @@ class _Engine:
         torch.cuda.current_stream().synchronize()       # `keep` may hold temporaries
         N.check(self.lib.sbgm_model_check_complete(self.h))
         self.version = ver
+        self._fast = self._fast_version(net)
 
     def download_bn_stats(self, net: "ScoreNet", n_forwards: int = 1):
         """train-mode forwards update the engine's running statistics; mirror them into the module buffers
@@ -288,6 +313,8 @@ class _Engine:
                     v += n_forwards
         sd = net.state_dict(keep_vars=True)
         self.version = (N.generation(),) + tuple((k, v.data_ptr(), v._version) for k, v in sd.items())
+        self._mods = None
+        self._fast = self._fast_version(net)
 
 
 class ScoreNet(nn.Module):

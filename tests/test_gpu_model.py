@@ -357,3 +357,25 @@ def test_standalone_submodule_calls_match_the_oracle(mode):
             assert maxrel(pn[k].grad.cpu(), po[k].grad) < tol, k
     with pytest.raises(AssertionError):                      # reference :596-597
         net.decoder.residual_layers[2](fn[2].detach(), fn[2].detach(), t.cuda())
+
+
+def test_cached_step_graph_is_reused_across_runs_with_other_seeds_and_lengths():
+    """the captured SDE step is kept in the model handle: a later run with another seed / num_steps / cond CONTENT (same tensors)
+    replays it — its result must equal eager launches of that run bit for bit; a run with other tensors re-captures"""
+    import sbgm_danra_amd as S
+    _, net, _ = build_pair(1)
+    net.eval()
+    g = torch.Generator().manual_seed(21)
+    cond = torch.randn(2, 1, 64, 64, generator=g).cuda()
+    for sampler in (S.Euler_Maruyama_sampler, S.pc_sampler):
+        kw = dict(batch_size=2, device="cuda", img_size=64, cond_img=cond)
+        sampler(net, S.marginal_prob_std_fn, S.diffusion_coeff_fn, num_steps=3, seed=9, use_graph=True, **kw)        # captures
+        cond.copy_(torch.randn(2, 1, 64, 64, generator=g))                                                            # same tensor, new content
+        a = sampler(net, S.marginal_prob_std_fn, S.diffusion_coeff_fn, num_steps=7, seed=1, use_graph=True, **kw)    # replays the cached step
+        b = sampler(net, S.marginal_prob_std_fn, S.diffusion_coeff_fn, num_steps=7, seed=1, use_graph=False, **kw)
+        assert torch.isfinite(a).all() and torch.equal(a, b)
+        cond2 = cond.clone()
+        c = sampler(net, S.marginal_prob_std_fn, S.diffusion_coeff_fn, num_steps=7, seed=1, use_graph=True, **dict(kw, cond_img=cond2))
+        assert torch.equal(c, a)
+        d = sampler(net, S.marginal_prob_std_fn, S.diffusion_coeff_fn, num_steps=7, seed=2, use_graph=True, **kw)
+        assert not torch.equal(d, a)
