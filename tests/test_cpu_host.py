@@ -101,7 +101,7 @@ def test_library_exports_every_declared_symbol():
     assert len(declared) >= 35
     assert declared == set(N.SIGNATURES), declared ^ set(N.SIGNATURES)
     lib = N.lib()                                # dlopen + resolve all of them (no compute, no GPU needed)
-    assert lib.sbgm_abi_version() == 3
+    assert lib.sbgm_abi_version() == N.ABI_VERSION
     raw = ctypes.CDLL(N.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name
@@ -346,3 +346,9 @@ def test_tile_sharding_is_world_size_invariant(tmp_path):
     _spawn(_tile_shard_case, tmp_path)
     assert (tmp_path / "ok0.pt").exists() and (tmp_path / "ok1.pt").exists()
     assert torch.equal(sample_tiles_sharded(7, _stub_tiles, (1, 4, 4), "cpu", 3), _stub_tiles(list(range(7))))      # world size 1
+
+
+def test_graft_entry_build_hook():
+    """The driver's build hook and the first command of INTEGRATION.md: make (a no-op when current) + dlopen + ABI check."""
+    import __graft_entry__ as G
+    G.build()
