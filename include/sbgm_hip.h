@@ -196,6 +196,12 @@ typedef struct sbgm_conv_args {
      * winograd bit 0 is set (w_packed stays the implicit-GEMM image for every other kernel).  NULL: as before, a call with
      * winograd bit 0 reads the Winograd image from w_packed. */
     const float* w_wino;
+    /* Optional third weight image for the 2-D Winograd F(2x2,3x3) LDS kernel (sbgm_conv_wino2d_pack_weight).  winograd bit 3 selects
+     * that kernel: 16x16-pixel tiles, tile_co in {1, 2} (16 / 32 output channels per workgroup), tile_px / splits ignored,
+     * waves_per_tile = 2 picks the build whose registers are held to two workgroups per CU, bit 2 = two LDS stage buffers; needs
+     * W %% 16 == 0 and an even H; all three in_mode values.  Weights: w_wino2d when given, else w_packed must be that image.
+     * When given, sbgm_conv2d_tune also times these candidates (tile[4] == 2 then means bit 3). */
+    const float* w_wino2d;
 } sbgm_conv_args;
 int sbgm_conv2d_fwd(const sbgm_conv_args* a, void* stream);
 /* Times the kernel / tile / split candidates for exactly this call (same operands; launches are idempotent; synchronises)
@@ -232,6 +238,10 @@ int sbgm_wgrad_flush_pending(void);
 /* Winograd F(2,3)-along-rows weight transform for 3x3 kernels: OIHW -> U[kh][c/16][xi][Cout][16] */
 int64_t sbgm_conv_wino_packed_numel(int Cout, int c_pad);
 int sbgm_conv_wino_pack_weight(const float* w_oihw, float* packed, int Cout, int Cin, int c_pad, void* stream);
+
+/* Winograd F(2x2,3x3) weight transform for 3x3 kernels: OIHW -> U[c/16][xi*4+eta][Cout][16], U = G g G^T */
+int64_t sbgm_conv_wino2d_packed_numel(int Cout, int c_pad);
+int sbgm_conv_wino2d_pack_weight(const float* w_oihw, float* packed, int Cout, int Cin, int c_pad, void* stream);
 
 /* ConvTranspose2d(k=2,s=2) = one 1x1 convolution to 4C channels (weights from sbgm_tconv_weight_to_oihw, bias repeated
  * 4x) followed by depth->space; its backward is space->depth followed by the 1x1 convolution's backward. */

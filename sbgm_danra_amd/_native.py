@@ -59,7 +59,7 @@ class ConvArgs(C.Structure):
                 ("residual", _vp), ("B", _i), ("H", _i), ("W", _i), ("c_pad", _i), ("Cout", _i), ("KH", _i), ("KW", _i),
                 ("stride", _i), ("pad", _i), ("act", _i), ("tbias_after_act", _i), ("tile_co", _i), ("tile_px", _i),
                 ("splits", _i), ("waves_per_tile", _i), ("winograd", _i), ("in_dil", _i), ("out_h", _i), ("out_w", _i), ("ws", _vp),
-                ("ws_floats", _i64), ("in_mode", _i), ("in_affine", _vp), ("in_skip", _vp), ("in_act", _i), ("w_wino", _vp)]
+                ("ws_floats", _i64), ("in_mode", _i), ("in_affine", _vp), ("in_skip", _vp), ("in_act", _i), ("w_wino", _vp), ("w_wino2d", _vp)]
 
 
 # name -> (restype, argtypes); every symbol include/sbgm_hip.h declares
@@ -98,6 +98,8 @@ SIGNATURES = {
     "sbgm_nhwc_to_nchw": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "sbgm_conv_packed_numel": (_i64, [_i, _i, _i, _i]),
     "sbgm_conv_pack_weight": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "sbgm_conv_wino2d_packed_numel": (_i64, [_i, _i]),
+    "sbgm_conv_wino2d_pack_weight": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "sbgm_conv2d_fwd": (_i, [C.POINTER(ConvArgs), _vp]),
     "sbgm_conv2d_tune": (_i, [C.POINTER(ConvArgs), C.POINTER(C.c_int), _vp]),
     "sbgm_conv_pack_weights_batched": (_i, [_vp, _i, _i, _vp]),
@@ -154,7 +156,7 @@ SIGNATURES = {
     "sbgm_randn_scaled": (_i, [_vp, _f, _u64, _u64, _i64, _vp]),
 }
 
-ABI_VERSION = 3          # include/sbgm_hip.h: sbgm_abi_version()
+ABI_VERSION = 4          # include/sbgm_hip.h: sbgm_abi_version()
 
 _lib = None
 

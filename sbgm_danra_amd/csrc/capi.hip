@@ -29,6 +29,10 @@ int64_t sbgm_conv_wino_packed_numel(int Cout, int c_pad) { return (int64_t)sbgm_
 int sbgm_conv_wino_pack_weight(const float* w_oihw, float* packed, int Cout, int Cin, int c_pad, void* stream) {
     return sbgm_launch_pack_wino_weight(w_oihw, packed, Cout, Cin, c_pad, ST);
 }
+int64_t sbgm_conv_wino2d_packed_numel(int Cout, int c_pad) { return (int64_t)sbgm_w2d_packed_floats(Cout, c_pad); }
+int sbgm_conv_wino2d_pack_weight(const float* w_oihw, float* packed, int Cout, int Cin, int c_pad, void* stream) {
+    return sbgm_launch_pack_w2d_weight(w_oihw, packed, Cout, Cin, c_pad, ST);
+}
 int sbgm_conv_pack_weight(const float* w_oihw, float* packed, int Cout, int Cin, int KH, int KW, int c_pad, void* stream) {
     return sbgm_launch_pack_conv_weight(w_oihw, packed, Cout, Cin, KH, KW, c_pad, ST);
 }
@@ -43,7 +47,14 @@ int sbgm_conv2d_fwd(const sbgm_conv_args* a, void* stream) {
     p.tbias_after_act = a->tbias_after_act;
     p.in_dil = a->in_dil; p.out_h = a->out_h; p.out_w = a->out_w;
     p.in_mode = a->in_mode; p.in_affine = a->in_affine; p.in_skip = a->in_skip; p.in_act = a->in_act;
-    SBGM_CHECK(a->in_mode == 0 || (a->winograd & 3) == 3, "conv2d: in_mode %d needs the LDS-staged Winograd kernel (winograd bits 0 and 1)", a->in_mode);
+    SBGM_CHECK(a->in_mode == 0 || (a->winograd & 3) == 3 || (a->winograd & 8), "conv2d: in_mode %d needs an LDS-staged Winograd kernel (winograd bits 0 and 1, or bit 3)", a->in_mode);
+    if (a->winograd & 8) {                   // 2-D Winograd F(2x2,3x3), LDS-staged (conv_w2d.hip): weights from sbgm_conv_wino2d_pack_weight
+        SBGM_CHECK(a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad == 1 && a->in_dil <= 1, "conv2d: the 2-D Winograd path is 3x3 stride 1 pad 1 only");
+        SBGM_CHECK(a->w_wino2d || !(a->winograd & 3), "conv2d: winograd bit 3 beside bits 0/1 needs w_wino2d");
+        if (a->w_wino2d) p.wp = a->w_wino2d;
+        const ConvTile t2{a->tile_co ? a->tile_co : 2, 1, 1, a->waves_per_tile == 2 ? 2 : 1, 2, (a->winograd & 4) ? 2 : 1};
+        return sbgm_launch_conv_w2d(p, t2, ST);
+    }
     if ((a->winograd & 1) && a->w_wino) p.wp = a->w_wino;
     ConvTile t{a->tile_co ? a->tile_co : (a->Cout % 64 == 0 ? 4 : 2), a->tile_px ? a->tile_px : 2, a->splits ? a->splits : 1,
                a->waves_per_tile ? a->waves_per_tile : 1, a->winograd & 1, (a->winograd & 2) ? ((a->winograd & 4) ? 2 : 1) : 0};
@@ -143,6 +154,7 @@ int sbgm_conv2d_tune(const sbgm_conv_args* a, int* tile, void* stream) {
     p.act = a->act; p.tbias_after_act = a->tbias_after_act;
     p.in_dil = a->in_dil; p.out_h = a->out_h; p.out_w = a->out_w;
     p.wp_wino = a->w_wino;
+    p.wp_w2d = a->w_wino2d;
     ConvTile best{a->Cout % 64 == 0 ? 4 : 2, 2, 1, 1, 0, 0};
     if (sbgm_tune_conv(ConvGeom{a->KH, a->KW, a->stride, a->pad}, p, a->ws, a->ws ? (size_t)a->ws_floats : 0, ST, &best)) return 1;
     tile[0] = best.fco; tile[1] = best.fpx; tile[2] = best.splits; tile[3] = best.ws; tile[4] = best.wino; tile[5] = best.lds;

@@ -37,6 +37,8 @@ struct Param {
     bool wino = false;          // 3x3 stride-1 conv: keep a Winograd F(2,3) packed copy as well
     float* dev_wino = nullptr;
     size_t wino_floats = 0;
+    float* dev_w2d = nullptr;   // ... and a 2-D Winograd F(2x2,3x3) packed copy (conv_w2d.hip)
+    size_t w2d_floats = 0;
     bool filled = false;
 };
 
@@ -45,6 +47,18 @@ struct BNW { Param *g, *b, *rm, *rv; float *scale, *bias; };       // + folded e
 struct AttnW { Param *ln1g, *ln1b, *ln2g, *ln2b, *inw, *inb, *outw, *outb, *f1w, *f1b, *f2w, *f2b; int C; };
 struct BlockW { ConvW c1, c2, ds; BNW bn1, bn2, dsbn; bool has_ds; int cin, cout, stride; };
 struct DecW { ConvW up, conv; Param *n1g, *n1b, *n2g, *n2b, *freq, *tpw, *tpb; AttnW attn; bool has_attn; int cin, cout; };
+
+// one launch of a tuned tile: picks the kernel family and the weight image it reads
+int launch_tile(const ConvGeom& g, ConvParams p, const ConvTile& ct, float* partial, hipStream_t st) {
+    if (ct.wino == 2) { p.wp = p.wp_w2d; return sbgm_launch_conv_w2d(p, ct, st); }
+    if (!ct.wino && !ct.lds) return sbgm_launch_conv(g, p, ct, partial, st);
+    if (ct.wino) p.wp = p.wp_wino;
+    return ct.lds ? sbgm_launch_conv_lds(p, ct, st) : sbgm_launch_conv_wino(p, ct, st);
+}
+// GroupNorm statistics the launch above leaves in p.gn_stats (chunks per sample), 0 = none
+int tile_gn_chunks(const ConvParams& p, const ConvTile& ct) {
+    return ct.wino == 2 ? sbgm_conv_w2d_gn_chunks(p, ct) : sbgm_conv_lds_gn_chunks(p, ct);
+}
 
 struct ConvOpKey {
     int kh, kw, s, p, B, H, W, Cs, Cout, proj, in_mode;
@@ -177,11 +191,7 @@ struct sbgm_model {
     int fold_bn(hipStream_t st);
     ConvTile pick_tile(const ConvGeom& g, const ConvParams& p);
     int conv(const ConvGeom& g, ConvParams p, hipStream_t st);
-    int launch_any(const ConvGeom& g, ConvParams p, const ConvTile& ct, hipStream_t st) {
-        if (!ct.wino && !ct.lds) return sbgm_launch_conv(g, p, ct, partial, st);
-        if (ct.wino) p.wp = p.wp_wino;
-        return ct.lds ? sbgm_launch_conv_lds(p, ct, st) : sbgm_launch_conv_wino(p, ct, st);
-    }
+    int launch_any(const ConvGeom& g, ConvParams p, const ConvTile& ct, hipStream_t st) { return launch_tile(g, p, ct, partial, st); }
     int attention(const AttnW& a, float* x, int B, int S, hipStream_t st);
     int forward(const float* x, const float* t, const int64_t* y, const float* cond, const float* lsm, const float* topo,
                 float* out, float* const* fmaps_out, int B, int H, int W, int bn_train, hipStream_t st);
@@ -291,7 +301,8 @@ int sbgm_model::build(const sbgm_model_config& c) {
         else if (p->kind == P_IGNORE) p->dev_floats = 0;
         else p->dev_floats = (size_t)p->numel;
         if (p->wino) p->wino_floats = sbgm_wino_packed_floats(p->cout, p->cs);
-        total += align_up(p->dev_floats, 64) + align_up(p->wino_floats, 64);
+        if (p->wino && getenv("SBGM_NO_WINOGRAD2D") == nullptr) p->w2d_floats = sbgm_w2d_packed_floats(p->cout, p->cs);
+        total += align_up(p->dev_floats, 64) + align_up(p->wino_floats, 64) + align_up(p->w2d_floats, 64);
     }
     // folded BN scale/bias
     size_t bn_floats = 0;
@@ -307,6 +318,7 @@ int sbgm_model::build(const sbgm_model_config& c) {
         Param* p = up.get();
         if (p->dev_floats) { p->dev = arena + off; off += align_up(p->dev_floats, 64); }
         if (p->wino_floats) { p->dev_wino = arena + off; off += align_up(p->wino_floats, 64); }
+        if (p->w2d_floats) { p->dev_w2d = arena + off; off += align_up(p->w2d_floats, 64); }
         if (p->kind == P_IGNORE) p->filled = true;
     }
     auto place_bn = [&](BNW& b, int c_) {
@@ -394,12 +406,7 @@ int sbgm_tune_conv(const ConvGeom& g, const ConvParams& p, float* partial, size_
     const int OW = p.out_w > 0 ? p.out_w : (p.W + 2 * g.pad - g.kw) / g.stride + 1;
     const size_t mc = (size_t)p.B * OH * OW * p.Cout;
     const int nsteps = sbgm_conv_nsteps(g.kh, g.kw, p.c_real == 2 ? 2 : p.Cs);
-    auto launch = [&](const ConvTile& ct) -> int {
-        ConvParams q = p;
-        if (!ct.wino && !ct.lds) return sbgm_launch_conv(g, q, ct, partial, st);
-        if (ct.wino) q.wp = q.wp_wino;
-        return ct.lds ? sbgm_launch_conv_lds(q, ct, st) : sbgm_launch_conv_wino(q, ct, st);
-    };
+    auto launch = [&](const ConvTile& ct) -> int { return launch_tile(g, p, ct, partial, st); };
     std::vector<ConvTile> cands;
     const int tiles[6][2] = {{4, 4}, {4, 2}, {4, 1}, {2, 4}, {2, 2}, {2, 1}};
     for (auto& t : tiles) {
@@ -448,6 +455,18 @@ int sbgm_tune_conv(const ConvGeom& g, const ConvParams& p, float* partial, size_
                 if (sbgm_conv_lds_bytes(ConvTile{t[0], t[1], 1, 1, 1, 2}, p.in_mode) <= 160 * 1024) cands.push_back(ConvTile{t[0], t[1], 1, 1, 1, 2});
             }
     }
+    // 2-D Winograd F(2x2,3x3), LDS-staged: 16x16-pixel tiles, 16 or 32 channels per workgroup; a tap projection may span several
+    // channel tiles (partial planes).  ws = 2 selects the build that is held to two waves per SIMD.
+    if (p.wp_w2d != nullptr && s1 && p.W % 16 == 0 && p.H % 2 == 0 && p.Cs % 16 == 0 && getenv("SBGM_NO_LDS_CONV") == nullptr)
+        for (int fco : {2, 1}) {
+            if (p.Cout % (16 * fco)) continue;
+            for (int lds : {1, 2})
+                for (int ws : {1, 2}) {
+                    const ConvTile ct{fco, 1, 1, ws, 2, lds};
+                    if (fco == 1 && ws == 2) continue;
+                    if (sbgm_conv_w2d_bytes(ct, p.in_mode) <= 160 * 1024) cands.push_back(ct);
+                }
+        }
     hipEvent_t e0, e1;
     SBGM_HIP(hipEventCreate(&e0));
     SBGM_HIP(hipEventCreate(&e1));
@@ -626,7 +645,7 @@ int sbgm_model::forward(const float* x, const float* t, const int64_t* y, const 
     auto conv_bn = [&](const ConvGeom& g, const float* in, int h, int w, int cs, const ConvW& cw, BNW& bnw, int cout,
                        const float* res, bool relu, const float* tb_after, float* o) -> int {
         ConvParams p{};
-        p.x = in; p.wp = cw.w->dev; p.wp_wino = cw.w->dev_wino; p.B = B; p.H = h; p.W = w; p.Cs = cs; p.Cout = cout;
+        p.x = in; p.wp = cw.w->dev; p.wp_wino = cw.w->dev_wino; p.wp_w2d = cw.w->dev_w2d; p.B = B; p.H = h; p.W = w; p.Cs = cs; p.Cout = cout;
         if (!bn_train) {
             p.out = o; p.scale = bnw.scale; p.bias = bnw.bias; p.res = res; p.act = relu ? SBGM_ACT_RELU : SBGM_ACT_NONE;
             p.tbias = tb_after; p.tbias_after_act = 1;
@@ -713,7 +732,7 @@ int sbgm_model::forward(const float* x, const float* t, const int64_t* y, const 
     // conv_up of a block: input `in` [B][ch][cw_][ci] (or the pending raw map), output raw [B][2ch][2cw_][ci] (+ bias)
     auto conv_up = [&](const ConvW& cw, const float* in, int ci, int oh, int ow, ConvParams& p, float* out_raw) -> int {
         p = ConvParams{};
-        p.wp = cw.w->dev; p.wp_wino = cw.w->dev_wino; p.out = out_raw; p.bias = cw.b->dev; p.B = B; p.H = oh; p.W = ow; p.Cs = ci; p.Cout = ci;
+        p.wp = cw.w->dev; p.wp_wino = cw.w->dev_wino; p.wp_w2d = cw.w->dev_w2d; p.out = out_raw; p.bias = cw.b->dev; p.B = B; p.H = oh; p.W = ow; p.Cs = ci; p.Cout = ci;
         if (can_fuse(cw, ci, ow)) {
             p.in_mode = 2;
             p.x = pend.live ? pend.raw : in;
@@ -747,14 +766,14 @@ int sbgm_model::forward(const float* x, const float* t, const int64_t* y, const 
             if (conv_up(d.up, cur, d.cin, oh, ow, p, a)) return 1;
             p.gn_stats = stats; p.gn_groups = groups(d.cin);        // GroupNorm statistics in the epilogue when the LDS kernel runs
             if (conv(ConvGeom{3, 3, 1, 1}, p, st)) return 1;
-            gn1_chunks = sbgm_conv_lds_gn_chunks(p, last_tile);
+            gn1_chunks = tile_gn_chunks(p, last_tile);
         }
         float* c2 = wsalloc((size_t)B * oh * ow * d.cout);
         if (!c2) return 1;
         if (ensure_stats(a, oh * ow, d.cin, gn1_chunks)) return 1;
         p = ConvParams{};
         p.B = B; p.H = oh; p.W = ow; p.Cs = d.cin;
-        p.x = a; p.wp = d.conv.w->dev; p.wp_wino = d.conv.w->dev_wino; p.out = c2; p.bias = d.conv.b->dev; p.Cout = d.cout;
+        p.x = a; p.wp = d.conv.w->dev; p.wp_wino = d.conv.w->dev_wino; p.wp_w2d = d.conv.w->dev_w2d; p.out = c2; p.bias = d.conv.b->dev; p.Cout = d.cout;
         if (can_fuse(d.conv, d.cin, ow)) {           // norm1 applied while `conv` stages its patch
             float* aff1 = wsalloc((size_t)B * d.cin * 2);
             if (!aff1) return 1;
@@ -765,7 +784,7 @@ int sbgm_model::forward(const float* x, const float* t, const int64_t* y, const 
                                                SBGM_ACT_NONE, B, oh * ow, d.cin, groups(d.cin), GN_EPS, stats, gn1_chunks, st)) return 1;
         p.gn_stats = stats; p.gn_groups = groups(d.cout);
         if (conv(ConvGeom{3, 3, 1, 1}, p, st)) return 1;
-        int gn2_chunks = sbgm_conv_lds_gn_chunks(p, last_tile);
+        int gn2_chunks = tile_gn_chunks(p, last_tile);
         if (ensure_stats(c2, oh * ow, d.cout, gn2_chunks)) return 1;
         const ConvW& next_up = i < 3 ? dec[i + 1].up : fin_up;
         if (!d.has_attn && can_fuse(next_up, d.cout, 2 * ow)) {
@@ -799,11 +818,12 @@ int sbgm_model::forward(const float* x, const float* t, const int64_t* y, const 
         if (ci == 64) {
             // conv_up's 64-channel output feeds only the linear 3x3 Cout=1 conv: project onto its 9 taps in the epilogue
             // (9 floats per pixel instead of 64) and finish with a 9-point gather.
-            float* d = wsalloc((size_t)9 * B * H * W);
+            float* d = wsalloc((size_t)9 * B * H * W * 4);      // up to 4 partial planes (2-D Winograd tiles of 16 channels)
             if (!d) return 1;
             p.out = d; p.proj_w = fin_conv.w->dev; p.proj_out = d;
             if (conv(ConvGeom{3, 3, 1, 1}, p, st)) return 1;
-            if (sbgm_launch_tap_stencil(d, fin_conv.b->dev, t, cfg.sigma, out, B, H, W, st)) return 1;
+            const int parts = last_tile.wino == 2 ? sbgm_conv_w2d_proj_parts(p, last_tile) : 1;
+            if (sbgm_launch_tap_stencil(d, fin_conv.b->dev, t, cfg.sigma, out, B, H, W, st, parts)) return 1;
         } else {
             float* a = wsalloc((size_t)B * H * W * ci);
             if (!a) return 1;
@@ -1014,7 +1034,7 @@ const char* sbgm_get_error();
 extern "C" {
 
 const char* sbgm_last_error(void) { return sbgm_get_error(); }
-int sbgm_abi_version(void) { return 3; }
+int sbgm_abi_version(void) { return 4; }
 int sbgm_model_config_size(void) { return (int)sizeof(sbgm_model_config); }
 
 int sbgm_model_create(const sbgm_model_config* cfg, sbgm_model** out) {
@@ -1049,6 +1069,7 @@ int sbgm_model_set_param(sbgm_model* m, const char* name, const void* data, int6
     } else if (p->kind == P_CONV) {
         if (sbgm_launch_pack_conv_weight(src, p->dev, p->cout, p->cin, p->kh, p->kw, p->cs, st)) return 1;
         if (p->wino && sbgm_launch_pack_wino_weight(src, p->dev_wino, p->cout, p->cin, p->cs, st)) return 1;
+        if (p->dev_w2d && sbgm_launch_pack_w2d_weight(src, p->dev_w2d, p->cout, p->cin, p->cs, st)) return 1;
     } else if (p->kind == P_TCONV) {             // [Cin][Cout][2][2] -> OIHW [4*Cout][Cin][1][1] (scratch) -> packed
         float* tmp = nullptr;
         SBGM_HIP(hipMalloc(&tmp, (size_t)numel * 4));
@@ -1121,7 +1142,8 @@ int sbgm_model_autotune(sbgm_model* m, int B, int H, int W, void* stream) {
 extern "C++" {
 static std::string conv_kernel_name(const sbgm_model::ConvRec& r) {
     char b[96];
-    if (r.t.lds) snprintf(b, sizeof b, "conv3x3_lds_kernel<%d; %d; %s; %s; %d>", r.t.fco, r.t.fpx, r.t.wino ? "true" : "false", r.t.lds == 2 ? "true" : "false", r.in_mode);
+    if (r.t.wino == 2) snprintf(b, sizeof b, "conv3x3_w2d_kernel<%d; %d; %s; %d>", r.t.fco, r.t.ws == 2 ? 2 : 1, r.t.lds == 2 ? "true" : "false", r.in_mode);
+    else if (r.t.lds) snprintf(b, sizeof b, "conv3x3_lds_kernel<%d; %d; %s; %s; %d>", r.t.fco, r.t.fpx, r.t.wino ? "true" : "false", r.t.lds == 2 ? "true" : "false", r.in_mode);
     else if (r.t.wino) snprintf(b, sizeof b, "conv3x3_wino_kernel<%d; %d; %d>", r.t.fco, r.t.fpx, r.t.ws);
     else snprintf(b, sizeof b, "conv_igemm_kernel<%d; %d; %d; %d; %d; %d; %d; %d>", r.g.kh, r.g.kw, r.g.stride, r.g.pad, r.t.fco,
                   r.t.fpx, r.c_real == 2 ? 2 : (r.Cs >= 16 ? 0 : r.Cs), r.t.ws);
@@ -1161,7 +1183,7 @@ int sbgm_model_tune_load(sbgm_model* m, const char* path) {
                              &k.Cs, &k.Cout, &k.proj, &k.in_mode, &t[0], &t[1], &t[2], &t[3], &t[4], &t[5]);
         // the launchers reject tiles they do not instantiate; here only the ranges that index memory are checked
         const bool ok = n == 17 && k.in_mode >= 0 && k.in_mode <= 2 && (t[0] == 1 || t[0] == 2 || t[0] == 4) && (t[1] == 1 || t[1] == 2 || t[1] == 4) && t[2] >= 1 &&
-                        t[2] <= 64 && (t[3] == 1 || t[3] == 2 || t[3] == 4 || t[3] == 8) && (t[4] | 1) == 1 && t[5] >= 0 && t[5] <= 2 &&
+                        t[2] <= 64 && (t[3] == 1 || t[3] == 2 || t[3] == 4 || t[3] == 8) && t[4] >= 0 && t[4] <= 2 && (t[4] != 2 || t[5] >= 1) && t[5] >= 0 && t[5] <= 2 &&
                         k.Cout % (16 * t[0]) == 0;
         if (!ok) {
             fclose(f);
@@ -1208,7 +1230,7 @@ int sbgm_model_profile_forward(sbgm_model* m, const float* x, const float* t, co
         s.n_conv += 1;
         if (r.ms > s.ms_conv_max) { s.ms_conv_max = r.ms; s.flops_conv_max = r.flops; }
         if (f) fprintf(f, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%.4f,%.4f,%.2f,%s\n", i, r.g.kh, r.g.kw, r.g.stride, r.B, r.H, r.W,
-                       r.Cs, r.Cout, r.M, r.nsteps, 16 * r.t.fco, r.t.lds ? 64 * r.t.fpx * (r.t.wino ? 2 : 1) : (r.t.wino ? 32 : 16) * r.t.fpx, r.t.splits, r.t.lds ? (r.t.wino ? -20 : 20) : (r.t.wino ? -r.t.ws : r.t.ws), r.flops * 1e-9, r.ms,
+                       r.Cs, r.Cout, r.M, r.nsteps, 16 * r.t.fco, r.t.wino == 2 ? 256 : r.t.lds ? 64 * r.t.fpx * (r.t.wino ? 2 : 1) : (r.t.wino ? 32 : 16) * r.t.fpx, r.t.splits, r.t.wino == 2 ? -40 : r.t.lds ? (r.t.wino ? -20 : 20) : (r.t.wino ? -r.t.ws : r.t.ws), r.flops * 1e-9, r.ms,
                        r.flops / (r.ms * 1e-3) * 1e-12, conv_kernel_name(r).c_str());
         ++i;
     }

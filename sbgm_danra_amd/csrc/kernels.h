@@ -12,7 +12,8 @@ struct ConvTile {
     int fco, fpx;   // wave tile = (16*fco) output channels x (16*fpx) pixels
     int splits;     // split-K over gridDim.y (partials + reduce kernel)
     int ws;         // waves of a workgroup cooperating on one tile (in-workgroup split-K through LDS): 1, 2 or 4
-    int wino;       // 1 = 3x3/s1 Winograd F(2,3) kernel (conv_wino.hip): fpx then counts PAIR fragments, weights = wino pack
+    int wino;       // 1 = 3x3/s1 Winograd F(2,3) kernel (conv_wino.hip): fpx then counts PAIR fragments, weights = wino pack;
+                    // 2 = 2-D Winograd F(2x2,3x3), LDS-staged only (conv_w2d.hip): 16x16-pixel tiles, fpx unused, weights = w2d pack
     int lds;        // 1 = LDS-staged 3x3/s1 kernel (conv_lds.hip): fpx = tile rows per wave (Winograd: 2*fpx rows)
 };
 struct ConvParams {
@@ -28,6 +29,7 @@ struct ConvParams {
     const float* proj_w;  // [9][Cout] or null: fuse the following 3x3 Cout=1 conv's per-tap channel dot products
     float* proj_out;      // [9][M] planar tap sums (then `out` is not written)
     const float* wp_wino; // host-side only: Winograd-packed copy of the weights (3x3 stride-1 layers), or null
+    const float* wp_w2d;  // host-side only: F(2x2,3x3)-packed copy of the weights (3x3 stride-1 layers), or null
     double* gn_stats;     // conv_lds only, or null: per-workgroup GroupNorm partial sums of the OUTPUT (sum, sum of squares per
                           // group) in the [b][chunk][G][2] layout groupnorm_apply reads -> no separate statistics pass
     int gn_groups;        // G of that GroupNorm (channels per group must divide or be a multiple of the tile's channel slice)
@@ -77,6 +79,15 @@ size_t sbgm_conv_lds_bytes(const ConvTile& cfg, int in_mode);
 // chunks per sample the launch above writes into p.gn_stats for this tile, or 0 if that tile cannot produce them
 int sbgm_conv_lds_gn_chunks(const ConvParams& p, const ConvTile& cfg);
 
+// ---- conv_w2d.hip: the same convolution as a 2-D Winograd F(2x2,3x3), LDS-staged (ConvTile.wino == 2) -----------------------
+size_t sbgm_w2d_packed_floats(int Cout, int cs);
+int sbgm_launch_pack_w2d_weight(const float* w_oihw, float* up, int Cout, int Cin, int cs, hipStream_t st);
+int sbgm_launch_conv_w2d(ConvParams p, const ConvTile& cfg, hipStream_t st);    // p.wp = F(2x2,3x3)-packed weights
+size_t sbgm_conv_w2d_bytes(const ConvTile& cfg, int in_mode);
+int sbgm_conv_w2d_gn_chunks(const ConvParams& p, const ConvTile& cfg);
+// co tiles of a tap-projection launch: each writes its own partial plane [tile][9][M], sbgm_launch_tap_stencil sums `parts` planes
+int sbgm_conv_w2d_proj_parts(const ConvParams& p, const ConvTile& cfg);
+
 // ---- pointwise.hip ---------------------------------------------------------------------------------
 struct PackSrc {
     const float* ptr[4];   // NCHW sources, concatenated along C in this order
@@ -120,7 +131,7 @@ int sbgm_launch_conv3x3_cout1(const float* x, const float* w_tap_c, const float*
                               float* out, int B, int H, int W, int C, hipStream_t st);
 // out[b,y,x] = (bias + sum_taps d[tap][b, y+kh-1, x+kw-1]) / sigma(t_b): finishes the fused final conv
 int sbgm_launch_tap_stencil(const float* d, const float* bias, const float* t, float sigma, float* out, int B, int H, int W,
-                            hipStream_t st);
+                            hipStream_t st, int parts = 1);   // parts: partial planes [parts][9][M] summed on the way
 int sbgm_launch_pack_cout1_weight(const float* w_oihw, float* w_tap_c, int C, hipStream_t st);
 
 // ---- norm.hip ------------------------------------------------------------------------------------------

@@ -243,7 +243,7 @@ __global__ __launch_bounds__(256) void conv3x3_cout1_kernel(const float* __restr
 // Finish of the fused final block: 9-point gather over the planar per-tap sums written by the conv_up epilogue.
 __global__ __launch_bounds__(256) void tap_stencil_kernel(const float* __restrict__ d, const float* __restrict__ bias,
                                                           const float* __restrict__ t, float sigma, float* __restrict__ out,
-                                                          int B, int H, int W) {
+                                                          int B, int H, int W, int parts) {
     const size_t M = (size_t)B * H * W;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < M; i += (size_t)gridDim.x * blockDim.x) {
         const int x = (int)(i % W);
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(256) void tap_stencil_kernel(const float* __restric
             for (int kw = 0; kw < 3; ++kw) {
                 const int ix = x + kw - 1;
                 if ((unsigned)ix >= (unsigned)W) continue;
-                v += d[(size_t)(kh * 3 + kw) * M + ((size_t)b * H + iy) * W + ix];
+                for (int pt = 0; pt < parts; ++pt) v += d[(size_t)(pt * 9 + kh * 3 + kw) * M + ((size_t)b * H + iy) * W + ix];
             }
         }
         v += bias[0];
@@ -423,8 +423,8 @@ int sbgm_launch_conv3x3_cout1(const float* x, const float* w_tap_c, const float*
 }
 
 int sbgm_launch_tap_stencil(const float* d, const float* bias, const float* t, float sigma, float* out, int B, int H, int W,
-                            hipStream_t st) {
-    hipLaunchKernelGGL(tap_stencil_kernel, dim3(stream_blocks((size_t)B * H * W)), dim3(256), 0, st, d, bias, t, sigma, out, B, H, W);
+                            hipStream_t st, int parts) {
+    hipLaunchKernelGGL(tap_stencil_kernel, dim3(stream_blocks((size_t)B * H * W)), dim3(256), 0, st, d, bias, t, sigma, out, B, H, W, parts);
     SBGM_LAUNCH_CHECK();
     return 0;
 }

@@ -55,22 +55,25 @@ def gn_affine(x_nhwc_dev, gamma, beta, tbias, G):
 
 
 def fused_conv(x_nhwc_dev, w, bias, H, W, tile, db, in_mode, affine=None, skip=None, act=N.NONE):
+    """tile = (co fragments, rows per wave): the 1-D Winograd LDS kernel; tile = ("2d", co fragments, min waves per SIMD): conv_w2d.hip"""
     lib = N.lib()
     B, Cin = x_nhwc_dev.shape[0], x_nhwc_dev.shape[3]
     Cout = w.shape[0]
     wd = w.contiguous().to(DEV)
-    packed = torch.empty(lib.sbgm_conv_wino_packed_numel(Cout, Cin), device=DEV)
-    N.check(lib.sbgm_conv_wino_pack_weight(wd.data_ptr(), packed.data_ptr(), Cout, Cin, Cin, N.stream()))
+    w2d = tile[0] == "2d"
+    packed = torch.empty((lib.sbgm_conv_wino2d_packed_numel if w2d else lib.sbgm_conv_wino_packed_numel)(Cout, Cin), device=DEV)
+    N.check((lib.sbgm_conv_wino2d_pack_weight if w2d else lib.sbgm_conv_wino_pack_weight)(wd.data_ptr(), packed.data_ptr(), Cout, Cin, Cin, N.stream()))
     out = torch.empty(B, H, W, Cout, device=DEV)
     bd = bias.to(DEV)
+    tco, tpx, wpt, bits = (tile[1], 0, tile[2], 8) if w2d else (tile[0], tile[1], 0, 3)
     a = N.ConvArgs(x_nhwc_dev.data_ptr(), packed.data_ptr(), out.data_ptr(), None, bd.data_ptr(), None, None, B, H, W, Cin, Cout, 3, 3, 1, 1,
-                   N.NONE, 0, tile[0], tile[1], 0, 0, 3 | (4 if db else 0), 0, 0, 0, None, 0, in_mode, N.ptr(affine), N.ptr(skip), act)
+                   N.NONE, 0, tco, tpx, 0, wpt, bits | (4 if db else 0), 0, 0, 0, None, 0, in_mode, N.ptr(affine), N.ptr(skip), act)
     N.check(lib.sbgm_conv2d_fwd(C.byref(a), N.stream()))
     torch.cuda.synchronize()
     return nchw(out.cpu())
 
 
-TILES = [(4, 1), (4, 2), (2, 1), (2, 2), (1, 1), (1, 2)]
+TILES = [(4, 1), (4, 2), (2, 1), (2, 2), (1, 1), (1, 2), ("2d", 1, 1), ("2d", 2, 1), ("2d", 2, 2)]
 ACT = {N.NONE: lambda v: v, N.SILU: F.silu, N.RELU: F.relu, N.GELU: F.gelu}
 
 
@@ -79,7 +82,7 @@ ACT = {N.NONE: lambda v: v, N.SILU: F.silu, N.RELU: F.relu, N.GELU: F.gelu}
 @pytest.mark.parametrize("db", [False, True])
 def test_groupnorm_affine_on_load(shape, tile, db):
     B, Cin, H, W, Cout, G = shape
-    if Cout % (16 * tile[0]):
+    if Cout % (16 * (tile[1] if tile[0] == "2d" else tile[0])):
         pytest.skip("tile wider than Cout")
     affine_params = G != Cin                       # G == C: InstanceNorm2d, no affine (reference default norm)
     x, w, b = rnd(B, Cin, H, W) * 1.7 + 0.4, rnd(Cout, Cin, 3, 3, seed=1, scale=1.0 / math.sqrt(Cin * 9)), rnd(Cout, seed=2)
@@ -97,7 +100,7 @@ def test_groupnorm_affine_on_load(shape, tile, db):
 @pytest.mark.parametrize("pre", ["plain", "norm+skip+silu"])
 def test_bilinear_upsample_on_load(shape, tile, db, pre):
     B, Cin, H, W, Cout = shape                      # H, W: the convolution's (high-resolution) size
-    if Cout % (16 * tile[0]):
+    if Cout % (16 * (tile[1] if tile[0] == "2d" else tile[0])):
         pytest.skip("tile wider than Cout")
     h, w_ = H // 2, W // 2
     x, w, b = rnd(B, Cin, h, w_) * 1.3 - 0.2, rnd(Cout, Cin, 3, 3, seed=1, scale=1.0 / math.sqrt(Cin * 9)), rnd(Cout, seed=2)

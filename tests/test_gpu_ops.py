@@ -170,6 +170,53 @@ def test_conv_lds_staged(shape, mode, tile):
     assert relerr(got, ref_conv(x, w, 1, 1, **kw)) < 2e-5
 
 
+def run_wino2d(x, w, fco, minw, db, **kw):
+    """2-D Winograd F(2x2,3x3) LDS kernel (csrc/conv_w2d.hip) through sbgm_conv2d_fwd: winograd bit 3 (+ bit 2 = double-buffered)"""
+    B, Cin, H, W = x.shape
+    Cout = w.shape[0]
+    cp = pad_c(Cin)
+    xp = torch.zeros(B, H, W, cp)
+    xp[..., :Cin] = nhwc(x)
+    xd, wd = xp.to(DEV), w.contiguous().to(DEV)
+    packed = torch.empty(lib().sbgm_conv_wino2d_packed_numel(Cout, cp), device=DEV)
+    N.check(lib().sbgm_conv_wino2d_pack_weight(wd.data_ptr(), packed.data_ptr(), Cout, Cin, cp, N.stream()))
+    out = torch.empty(B, H, W, Cout, device=DEV)
+    dv = lambda t: None if t is None else t.contiguous().to(DEV)  # noqa: E731
+    sc, bi, tb, rs = dv(kw.get("scale")), dv(kw.get("bias")), dv(kw.get("tbias")), dv(None if kw.get("res") is None else nhwc(kw["res"]))
+    a = N.ConvArgs(xd.data_ptr(), packed.data_ptr(), out.data_ptr(), N.ptr(sc), N.ptr(bi), N.ptr(tb), N.ptr(rs), B, H, W, cp, Cout, 3, 3, 1, 1,
+                   N.RELU if kw.get("relu") else N.NONE, int(kw.get("after", False)), fco, 0, 0, minw, 8 | (4 if db else 0), 0, 0, 0, None, 0)
+    N.check(lib().sbgm_conv2d_fwd(C.byref(a), N.stream()))
+    torch.cuda.synchronize()
+    return nchw(out.cpu())
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 16, 16, 64), (1, 64, 32, 48, 128), (2, 128, 12, 16, 64), (1, 16, 20, 48, 32), (1, 256, 4, 16, 64),
+                                   (3, 32, 2, 16, 32), (1, 64, 34, 32, 64)])
+@pytest.mark.parametrize("fco,minw", [(1, 1), (2, 1), (2, 2)])
+@pytest.mark.parametrize("db", [False, True])
+def test_conv_winograd_f2x2_3x3(shape, fco, minw, db):
+    """nn.Conv2d(3, padding=1) (reference score_unet.py:468, :489, BasicBlock convs) on the 2-D Winograd kernel: ragged tile rows
+    (H = 2, 4, 12, 20, 34), several tiles per row, 1..16 channel stages, the full epilogue"""
+    B, Cin, H, W, Cout = shape
+    x, w = rnd(B, Cin, H, W), rnd(Cout, Cin, 3, 3, seed=1, scale=1.0 / math.sqrt(Cin * 9))
+    assert relerr(run_wino2d(x, w, fco, minw, db), ref_conv(x, w, 1, 1)) < 2e-5
+    kw = dict(scale=rnd(Cout, seed=3).abs() + 0.5, bias=rnd(Cout, seed=4), tbias=rnd(B, Cout, seed=5), res=rnd(B, Cout, H, W, seed=6),
+              relu=True, after=True)
+    assert relerr(run_wino2d(x, w, fco, minw, db, **kw), ref_conv(x, w, 1, 1, **kw)) < 2e-5
+
+
+def test_conv_winograd_f2x2_3x3_localised():
+    """element-wise check on a sparse input: one hot pixel per corner / edge / interior must reproduce the 3x3 stencil exactly
+    where a global-norm error measure would hide a wrong border coefficient"""
+    B, Cin, H, W, Cout = 1, 16, 32, 32, 32
+    x = torch.zeros(B, Cin, H, W)
+    for (yy, xx) in [(0, 0), (0, 31), (31, 0), (31, 31), (15, 16), (16, 15), (0, 17), (17, 0), (31, 14), (14, 31)]:
+        x[0, (yy + xx) % Cin, yy, xx] = 1.0 + 0.01 * yy
+    w = rnd(Cout, Cin, 3, 3, seed=9, scale=0.3)
+    got, want = run_wino2d(x, w, 2, 1, False), ref_conv(x, w, 1, 1)
+    assert float((got - want).abs().max()) < 2e-6
+
+
 def test_conv_winograd_epilogue():
     B, Cin, H, W, Cout = 2, 64, 8, 12, 64
     x, w = rnd(B, Cin, H, W), rnd(Cout, Cin, 3, 3, seed=2, scale=0.04)
