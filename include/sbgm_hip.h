@@ -198,9 +198,10 @@ typedef struct sbgm_conv_args {
     const float* w_wino;
     /* Optional third weight image for the 2-D Winograd F(2x2,3x3) LDS kernel (sbgm_conv_wino2d_pack_weight).  winograd bit 3 selects
      * that kernel: 16x16-pixel tiles, tile_co in {1, 2} (16 / 32 output channels per workgroup), tile_px / splits ignored,
-     * waves_per_tile = 2 picks the build whose registers are held to two workgroups per CU, bit 2 = two LDS stage buffers; needs
-     * W %% 16 == 0 and an even H; all three in_mode values.  Weights: w_wino2d when given, else w_packed must be that image.
-     * When given, sbgm_conv2d_tune also times these candidates (tile[4] == 2 then means bit 3). */
+     * waves_per_tile = 2 picks the build whose registers are held to two workgroups per CU, bit 2 = two LDS stage buffers, bit 4
+     * (16) = the persistent form (two workgroups per CU walk over the tiles, weight slab by LDS-DMA); needs W %% 16 == 0 and an
+     * even H; all three in_mode values.  Weights: w_wino2d when given, else w_packed must be that image.
+     * When given, sbgm_conv2d_tune also times these candidates (tile[4] == 2 then means bit 3; tile[5] == 3 means bit 4). */
     const float* w_wino2d;
 } sbgm_conv_args;
 int sbgm_conv2d_fwd(const sbgm_conv_args* a, void* stream);

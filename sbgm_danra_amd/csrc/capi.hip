@@ -52,7 +52,8 @@ int sbgm_conv2d_fwd(const sbgm_conv_args* a, void* stream) {
         SBGM_CHECK(a->KH == 3 && a->KW == 3 && a->stride == 1 && a->pad == 1 && a->in_dil <= 1, "conv2d: the 2-D Winograd path is 3x3 stride 1 pad 1 only");
         SBGM_CHECK(a->w_wino2d || !(a->winograd & 3), "conv2d: winograd bit 3 beside bits 0/1 needs w_wino2d");
         if (a->w_wino2d) p.wp = a->w_wino2d;
-        const ConvTile t2{a->tile_co ? a->tile_co : 2, 1, 1, a->waves_per_tile == 2 ? 2 : 1, 2, (a->winograd & 4) ? 2 : 1};
+        const ConvTile t2{a->tile_co ? a->tile_co : 2, 1, 1, (a->winograd & 16) ? 2 : (a->waves_per_tile == 2 ? 2 : 1), 2,
+                          (a->winograd & 16) ? 3 : (a->winograd & 4) ? 2 : 1};
         return sbgm_launch_conv_w2d(p, t2, ST);
     }
     if ((a->winograd & 1) && a->w_wino) p.wp = a->w_wino;

@@ -95,7 +95,7 @@ struct sbgm_model {
     std::map<ConvOpKey, ConvTile> tuned;
     ConvTile last_tile{};                   // tile of the most recent conv() (tells the caller whether GroupNorm statistics were fused)
     bool tuning = false;
-    struct ConvRec { ConvGeom g; int B, H, W, Cs, Cout, M, nsteps; ConvTile t; double flops; hipEvent_t e0, e1; float ms; int c_real; int in_mode; };
+    struct ConvRec { ConvGeom g; int B, H, W, Cs, Cout, M, nsteps; ConvTile t; double flops; hipEvent_t e0, e1; float ms; int c_real; int in_mode; int proj; };
     std::vector<ConvRec>* prof = nullptr;   // when set, conv() brackets every launch with events
     static constexpr int PROF_REPS = 4;
     hipStream_t graph_stream = nullptr;     // private capture stream (the caller's may be the legacy default stream)
@@ -466,6 +466,7 @@ int sbgm_tune_conv(const ConvGeom& g, const ConvParams& p, float* partial, size_
                     if (fco == 1 && ws == 2) continue;
                     if (sbgm_conv_w2d_bytes(ct, p.in_mode) <= 160 * 1024) cands.push_back(ct);
                 }
+            cands.push_back(ConvTile{fco, 1, 1, 2, 2, 3});       // persistent workgroups, LDS-DMA slab (two per CU)
         }
     hipEvent_t e0, e1;
     SBGM_HIP(hipEventCreate(&e0));
@@ -527,7 +528,7 @@ int sbgm_model::conv(const ConvGeom& g, ConvParams p, hipStream_t st) {
     if (ct.splits > 1 && mc * ct.splits > PARTIAL_FLOATS) ct.splits = (int)std::max<size_t>(1, PARTIAL_FLOATS / mc);
     last_tile = ct;
     if (!prof) return launch_any(g, p, ct, st);
-    ConvRec r{g, p.B, p.H, p.W, p.Cs, p.Cout, p.B * OH * OW, sbgm_conv_nsteps(g.kh, g.kw, p.c_real == 2 ? 2 : p.Cs), ct, 0.0, nullptr, nullptr, 0.f, p.c_real, p.in_mode};
+    ConvRec r{g, p.B, p.H, p.W, p.Cs, p.Cout, p.B * OH * OW, sbgm_conv_nsteps(g.kh, g.kw, p.c_real == 2 ? 2 : p.Cs), ct, 0.0, nullptr, nullptr, 0.f, p.c_real, p.in_mode, p.proj_w != nullptr};
     // algorithmic FLOPs: 2 * M * Cout * (KH*KW*Cin_real); Cs may be padded (only the stem conv), count real K there
     const int cin_real = (g.kh == 8 && p.Cs <= 16) ? cin_total : p.Cs;
     r.flops = 2.0 * r.M * p.Cout * (double)(g.kh * g.kw * cin_real);
@@ -1142,7 +1143,8 @@ int sbgm_model_autotune(sbgm_model* m, int B, int H, int W, void* stream) {
 extern "C++" {
 static std::string conv_kernel_name(const sbgm_model::ConvRec& r) {
     char b[96];
-    if (r.t.wino == 2) snprintf(b, sizeof b, "conv3x3_w2d_kernel<%d; %d; %s; %d>", r.t.fco, r.t.ws == 2 ? 2 : 1, r.t.lds == 2 ? "true" : "false", r.in_mode);
+    if (r.t.wino == 2 && r.t.lds == 3) snprintf(b, sizeof b, "conv3x3_w2dp_kernel<%d; %d; %s>", r.t.fco, r.in_mode, r.proj ? "true" : "false");
+    else if (r.t.wino == 2) snprintf(b, sizeof b, "conv3x3_w2d_kernel<%d; %d; %s; %d>", r.t.fco, r.t.ws == 2 ? 2 : 1, r.t.lds == 2 ? "true" : "false", r.in_mode);
     else if (r.t.lds) snprintf(b, sizeof b, "conv3x3_lds_kernel<%d; %d; %s; %s; %d>", r.t.fco, r.t.fpx, r.t.wino ? "true" : "false", r.t.lds == 2 ? "true" : "false", r.in_mode);
     else if (r.t.wino) snprintf(b, sizeof b, "conv3x3_wino_kernel<%d; %d; %d>", r.t.fco, r.t.fpx, r.t.ws);
     else snprintf(b, sizeof b, "conv_igemm_kernel<%d; %d; %d; %d; %d; %d; %d; %d>", r.g.kh, r.g.kw, r.g.stride, r.g.pad, r.t.fco,
@@ -1183,7 +1185,7 @@ int sbgm_model_tune_load(sbgm_model* m, const char* path) {
                              &k.Cs, &k.Cout, &k.proj, &k.in_mode, &t[0], &t[1], &t[2], &t[3], &t[4], &t[5]);
         // the launchers reject tiles they do not instantiate; here only the ranges that index memory are checked
         const bool ok = n == 17 && k.in_mode >= 0 && k.in_mode <= 2 && (t[0] == 1 || t[0] == 2 || t[0] == 4) && (t[1] == 1 || t[1] == 2 || t[1] == 4) && t[2] >= 1 &&
-                        t[2] <= 64 && (t[3] == 1 || t[3] == 2 || t[3] == 4 || t[3] == 8) && t[4] >= 0 && t[4] <= 2 && (t[4] != 2 || t[5] >= 1) && t[5] >= 0 && t[5] <= 2 &&
+                        t[2] <= 64 && (t[3] == 1 || t[3] == 2 || t[3] == 4 || t[3] == 8) && t[4] >= 0 && t[4] <= 2 && (t[4] != 2 || t[5] >= 1) && t[5] >= 0 && t[5] <= (t[4] == 2 ? 3 : 2) &&
                         k.Cout % (16 * t[0]) == 0;
         if (!ok) {
             fclose(f);

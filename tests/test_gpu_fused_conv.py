@@ -65,7 +65,9 @@ def fused_conv(x_nhwc_dev, w, bias, H, W, tile, db, in_mode, affine=None, skip=N
     N.check((lib.sbgm_conv_wino2d_pack_weight if w2d else lib.sbgm_conv_wino_pack_weight)(wd.data_ptr(), packed.data_ptr(), Cout, Cin, Cin, N.stream()))
     out = torch.empty(B, H, W, Cout, device=DEV)
     bd = bias.to(DEV)
-    tco, tpx, wpt, bits = (tile[1], 0, tile[2], 8) if w2d else (tile[0], tile[1], 0, 3)
+    tco, tpx, wpt, bits = (tile[1], 0, 0 if tile[2] == "p" else tile[2], 8 | (16 if tile[2] == "p" else 0)) if w2d else (tile[0], tile[1], 0, 3)
+    if w2d and tile[2] == "p":
+        db = False
     a = N.ConvArgs(x_nhwc_dev.data_ptr(), packed.data_ptr(), out.data_ptr(), None, bd.data_ptr(), None, None, B, H, W, Cin, Cout, 3, 3, 1, 1,
                    N.NONE, 0, tco, tpx, 0, wpt, bits | (4 if db else 0), 0, 0, 0, None, 0, in_mode, N.ptr(affine), N.ptr(skip), act)
     N.check(lib.sbgm_conv2d_fwd(C.byref(a), N.stream()))
@@ -73,7 +75,7 @@ def fused_conv(x_nhwc_dev, w, bias, H, W, tile, db, in_mode, affine=None, skip=N
     return nchw(out.cpu())
 
 
-TILES = [(4, 1), (4, 2), (2, 1), (2, 2), (1, 1), (1, 2), ("2d", 1, 1), ("2d", 2, 1), ("2d", 2, 2)]
+TILES = [(4, 1), (4, 2), (2, 1), (2, 2), (1, 1), (1, 2), ("2d", 1, 1), ("2d", 2, 1), ("2d", 2, 2), ("2d", 1, "p"), ("2d", 2, "p")]
 ACT = {N.NONE: lambda v: v, N.SILU: F.silu, N.RELU: F.relu, N.GELU: F.gelu}
 
 

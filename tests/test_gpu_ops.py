@@ -184,7 +184,8 @@ def run_wino2d(x, w, fco, minw, db, **kw):
     dv = lambda t: None if t is None else t.contiguous().to(DEV)  # noqa: E731
     sc, bi, tb, rs = dv(kw.get("scale")), dv(kw.get("bias")), dv(kw.get("tbias")), dv(None if kw.get("res") is None else nhwc(kw["res"]))
     a = N.ConvArgs(xd.data_ptr(), packed.data_ptr(), out.data_ptr(), N.ptr(sc), N.ptr(bi), N.ptr(tb), N.ptr(rs), B, H, W, cp, Cout, 3, 3, 1, 1,
-                   N.RELU if kw.get("relu") else N.NONE, int(kw.get("after", False)), fco, 0, 0, minw, 8 | (4 if db else 0), 0, 0, 0, None, 0)
+                   N.RELU if kw.get("relu") else N.NONE, int(kw.get("after", False)), fco, 0, 0, 0 if minw == "p" else minw,
+                   8 | (16 if minw == "p" else (4 if db else 0)), 0, 0, 0, None, 0)
     N.check(lib().sbgm_conv2d_fwd(C.byref(a), N.stream()))
     torch.cuda.synchronize()
     return nchw(out.cpu())
@@ -192,9 +193,11 @@ def run_wino2d(x, w, fco, minw, db, **kw):
 
 @pytest.mark.parametrize("shape", [(2, 64, 16, 16, 64), (1, 64, 32, 48, 128), (2, 128, 12, 16, 64), (1, 16, 20, 48, 32), (1, 256, 4, 16, 64),
                                    (3, 32, 2, 16, 32), (1, 64, 34, 32, 64)])
-@pytest.mark.parametrize("fco,minw", [(1, 1), (2, 1), (2, 2)])
+@pytest.mark.parametrize("fco,minw", [(1, 1), (2, 1), (2, 2), (1, "p"), (2, "p")])       # "p": the persistent LDS-DMA kernel
 @pytest.mark.parametrize("db", [False, True])
 def test_conv_winograd_f2x2_3x3(shape, fco, minw, db):
+    if minw == "p" and db:
+        pytest.skip("one persistent form")
     """nn.Conv2d(3, padding=1) (reference score_unet.py:468, :489, BasicBlock convs) on the 2-D Winograd kernel: ragged tile rows
     (H = 2, 4, 12, 20, 34), several tiles per row, 1..16 channel stages, the full epilogue"""
     B, Cin, H, W, Cout = shape
@@ -213,8 +216,20 @@ def test_conv_winograd_f2x2_3x3_localised():
     for (yy, xx) in [(0, 0), (0, 31), (31, 0), (31, 31), (15, 16), (16, 15), (0, 17), (17, 0), (31, 14), (14, 31)]:
         x[0, (yy + xx) % Cin, yy, xx] = 1.0 + 0.01 * yy
     w = rnd(Cout, Cin, 3, 3, seed=9, scale=0.3)
-    got, want = run_wino2d(x, w, 2, 1, False), ref_conv(x, w, 1, 1)
-    assert float((got - want).abs().max()) < 2e-6
+    want = ref_conv(x, w, 1, 1)
+    for minw in (1, "p"):
+        assert float((run_wino2d(x, w, 2, minw, False) - want).abs().max()) < 2e-6
+
+
+def test_conv_winograd_f2x2_3x3_persistent_many_tiles():
+    """more tiles than resident workgroups (2 per CU): every workgroup of the persistent kernel walks over several tiles of several
+    images and channel slices, with the stage pipeline running across the tile boundaries; B = 40 x 64 x 64 is 640 tiles x 4 slices"""
+    B, Cin, H, W, Cout = 40, 32, 64, 64, 64
+    x, w = rnd(B, Cin, H, W), rnd(Cout, Cin, 3, 3, seed=1, scale=1.0 / math.sqrt(Cin * 9))
+    kw = dict(bias=rnd(Cout, seed=4), res=rnd(B, Cout, H, W, seed=6), relu=True)
+    want = ref_conv(x, w, 1, 1, **kw)
+    for fco in (1, 2):
+        assert relerr(run_wino2d(x, w, fco, "p", False, **kw), want) < 2e-5
 
 
 def test_conv_winograd_epilogue():

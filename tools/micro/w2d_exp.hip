@@ -20,14 +20,6 @@
 // neighbours of a column pair (the interpolation's column taps fold into B, conv_lds.hip header); the sweep then only applies the
 // row half V[xi] = B^T W, 16 vector operations per block instead of 32.
 //
-// Two kernels share the layouts and the arithmetic:
-//   conv3x3_w2d_kernel   one tile per workgroup, register-staged slab and patch (single- or double-buffered stages)
-//   conv3x3_w2dp_kernel  PERSISTENT workgroups (two per CU, each walking over a contiguous range of tiles so the stage pipeline runs
-//                        across tile boundaries), weight slab by LDS-DMA in two rolling halves (no staging registers, no ds_write),
-//                        double-buffered halo patch, A fragments and patch rows requested one MFMA group ahead
-// The autotuner times both per layer (ConvTile.lds = 1 / 2: first kernel, 3: persistent kernel).  What the measurements say about
-// them is in DESIGN.md section 3.1.
-//
 // LDS layouts (conflict-free for every ds_read_b128 lane group, exhaustive check in tools/lds_bank_check.py):
 //   weight slab  [tap][co][4 quads], quad rotated by (co & 15) >> 1                          (as conv_lds.hip)
 //   raw patch    [row (stride 74 quads)][px][4 quads], quad rotated by 2 * (px >> 2)          (modes 0, 1)
@@ -230,10 +222,23 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_w2d_kernel(const ConvParams
         expand(0, 0);
         if (DB && CB > 1) { stage_load(1); stage_store_l(1); }
     }
+#ifdef EXP_NO_RESTAGE
+#define CBN 1
+#else
+#define CBN CB
+#endif
+#ifdef EXP_STAMP
+    unsigned long long st_sweep = 0, st_bar1 = 0, st_store = 0, st_bar0 = 0, t_a = __builtin_amdgcn_s_memtime(), t_b;
+    const unsigned long long t_start = t_a;
+#define STAMP(acc_) { t_b = __builtin_amdgcn_s_memtime(); acc_ += t_b - t_a; t_a = t_b; }
+#else
+#define STAMP(acc_)
+#endif
     for (int cb = 0; cb < CB; ++cb) {
         if (!DB) {
-            if (cb + 1 < CB) stage_load(cb + 1);
+            if (cb + 1 < CBN) stage_load(cb + 1);
             __syncthreads();
+            STAMP(st_bar0)
         } else {
             __syncthreads();                     // stage cb is visible; every wave has finished stage cb-1 (the other buffer)
             if (cb + 1 < CB) {
@@ -246,6 +251,68 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_w2d_kernel(const ConvParams
             pt = pt0 + (cb & 1) * STAGE_QUADS;
         }
 
+#ifdef EXP_PIPE
+        // ---- software-pipelined sweep: the LDS reads (A fragments of the next (xi, eta) group, patch rows of the next xi) are issued
+        // one step ahead of the MFMAs that consume them; V of the next xi is formed during the last two groups of the current xi
+        {
+            constexpr int RA[4] = {0, 1, 2, 1}, RB[4] = {2, 2, 1, 3};
+            auto ldrow = [&](int rr, int c) -> f32x4 {
+                if (IN == 2) return pt[(r0 + rr) * 128 + coff[c] + ((kq + 2 * (((r0 + rr) >> 1) & 1)) & 3)];
+                return pt[(r0 + rr) * SY + coff[c]];
+            };
+            f32x4 a_cur[FCO], a_nxt[FCO], V[4], Vn[4], da[4], db[4];
+#pragma unroll
+            for (int i = 0; i < FCO; ++i) a_cur[i] = wl[(16 * i) * 4 + aoff];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) { da[c] = ldrow(RA[0], c); db[c] = ldrow(RB[0], c); }
+#pragma unroll
+            for (int c = 0; c < 4; ++c) da[c] = da[c] - db[c];
+            if (IN == 2) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) V[c] = da[c];
+            } else {
+                V[0] = da[0] - da[2]; V[1] = da[1] + da[2]; V[2] = da[2] - da[1]; V[3] = da[1] - da[3];
+            }
+#pragma unroll
+            for (int g = 0; g < 16; ++g) {
+                const int xi = g >> 2, eta = g & 3;
+                if (g + 1 < 16) {
+#pragma unroll
+                    for (int i = 0; i < FCO; ++i) a_nxt[i] = wl[((g + 1) * NCO + 16 * i) * 4 + aoff];
+                }
+                if (eta == 0 && xi < 3) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) { da[c] = ldrow(RA[xi + 1], c); db[c] = ldrow(RB[xi + 1], c); }
+                }
+                if (eta == 2 && xi < 3) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) da[c] = xi + 1 == 1 ? da[c] + db[c] : da[c] - db[c];
+                }
+                if (eta == 3 && xi < 3) {
+                    if (IN == 2) {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) Vn[c] = da[c];
+                    } else {
+                        Vn[0] = da[0] - da[2]; Vn[1] = da[1] + da[2]; Vn[2] = da[2] - da[1]; Vn[3] = da[1] - da[3];
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+#pragma unroll
+                    for (int i = 0; i < FCO; ++i)
+                        acc[g][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[i][k], V[eta][k], acc[g][i], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < FCO; ++i) a_cur[i] = a_nxt[i];
+                if (eta == 3 && xi < 3) {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) V[c] = Vn[c];
+                }
+#ifdef EXP_SCHEDBAR
+                __builtin_amdgcn_sched_barrier(0);
+#endif
+            }
+        }
+#else
         // ---- sweep: per xi the row combination of two patch rows, the column transform, then 4 eta x FCO x 4 MFMAs -----------
 #pragma unroll
         for (int xi = 0; xi < 4; ++xi) {
@@ -262,14 +329,22 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_w2d_kernel(const ConvParams
                     da = pt[(r0 + rra) * SY + coff[c]];
                     db = pt[(r0 + rrb) * SY + coff[c]];
                 }
+#ifdef EXP_NO_XFORM
+                T[c] = da; asm volatile("" :: "v"(db));
+#else
                 T[c] = xi == 1 ? da + db : da - db;
+#endif
             }
             f32x4 V[4];
             if (IN == 2) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) V[c] = T[c];
             } else {
+#ifdef EXP_NO_XFORM
+                V[0] = T[0]; V[1] = T[1]; V[2] = T[2]; V[3] = T[3];
+#else
                 V[0] = T[0] - T[2]; V[1] = T[1] + T[2]; V[2] = T[2] - T[1]; V[3] = T[1] - T[3];
+#endif
             }
             if (FCO == 1) {
                 // one accumulator per (xi, eta): k outermost so consecutive MFMAs go to 4 different accumulators
@@ -295,19 +370,29 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_w2d_kernel(const ConvParams
                 }
             }
         }
+#endif
         if (!DB) {
+            STAMP(st_sweep)
             if (IN == 2 && cb + 1 < CB) stage_store_l(0);    // the L region was last read before this stage's first barrier
             __syncthreads();                     // every wave is done reading this stage
-            if (cb + 1 < CB) {
+            STAMP(st_bar1)
+            if (cb + 1 < CBN) {
                 stage_store_w(0);
                 if (IN != 2) stage_store_p(0);
                 else expand(0, 0);
             }
+            STAMP(st_store)
         } else if (IN == 2 && cb + 2 < CB) {
             stage_store_l(cb & 1);
         }
     }
 
+#ifdef EXP_STAMP
+    if (p.proj_w == nullptr && p.proj_out != nullptr && lane == 0) {
+        unsigned long long* o = reinterpret_cast<unsigned long long*>(p.proj_out) + ((size_t)blockIdx.x * 4 + wave) * 8;
+        o[0] = st_bar0; o[1] = st_sweep; o[2] = st_bar1; o[3] = st_store; o[4] = t_a - t_start; o[5] = t_start;
+    }
+#endif
     // ---- epilogue: Y = A^T M A, then the shared convolution epilogue on the block's 4 pixels ---------------------------------
     const bool want_stats = p.gn_stats != nullptr;          // uniform
     f32x4 gs[FCO], gs2[FCO];
@@ -415,424 +500,6 @@ __global__ __launch_bounds__(256, MINW) void conv3x3_w2d_kernel(const ConvParams
     }
 }
 
-// ---- persistent form -----------------------------------------------------------------------------------------------------------
-// Stage pipeline (one stage = 16 input channels).  Weight slab [16 taps][NCO][16 ch] in LDS, single copy, two halves: H0 = taps of
-// xi 0,1 and H1 = taps of xi 2,3.  Halo patch, two copies (mode 2: one copy of the column-transformed rows + the low-res region).
-//     E(s-1) | DMA H1(s) ; global loads of patch(s+1) -> registers | sweep xi 0,1 of stage s (reads H0(s), patch(s))
-//     M(s)   | DMA H0(s+1)                                          | sweep xi 2,3 of stage s (reads H1(s), patch(s))
-//            | patch(s+1) registers -> other patch copy ; last stage of a tile: output transform, epilogue, stores
-//     E(s)   | ...
-// E and M are workgroup barriers behind an explicit s_waitcnt vmcnt(0) of every wave (an LDS-DMA is a pending LDS write on that
-// counter): a slab half is read only after the issuing waves' wait AND a barrier, and is overwritten only after a barrier every
-// reader has passed.  Each DMA half has half a sweep to land.  Mode 2 needs a third barrier per stage (E | expand | X | sweep).
-typedef const __attribute__((address_space(1))) void* gptr_t;
-typedef __attribute__((address_space(3))) void* lptr_t;
-
-template <int FCO, int IN, bool PROJ>
-__global__ __launch_bounds__(256, 2) void conv3x3_w2dp_kernel(const ConvParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-    constexpr int NCO = 16 * FCO;
-    constexpr int WQ = 16 * NCO * 4;                            // slab quads
-    constexpr int HQ = WQ / 2;                                  // quads of one slab half
-    constexpr int PQ = PH * PWID * 4;                           // raw patch quads loaded per stage
-    constexpr int PREG = IN == 2 ? PH * 4 * 8 * 4 : PH * SY;    // one patch copy, quads
-    constexpr int NPB = IN == 2 ? 1 : 2;                        // patch copies
-    constexpr int LH = TH / 2 + 2, LW = TW / 2 + 2;             // IN == 2: low-resolution pixels under the patch
-    constexpr int LQ = LH * LW * 4;
-    f32x4* const wl = reinterpret_cast<f32x4*>(smem_raw);      // [tap][co][4 quads]
-    f32x4* const pt0 = wl + WQ;                                 // patch copies
-    f32x4* const lr0 = pt0 + NPB * PREG;                        // IN == 2: L region [LH][LW][4 quads]
-    float* const red = reinterpret_cast<float*>(lr0 + (IN == 2 ? LQ : 0));   // GroupNorm statistics scratch [4 waves][NCO][2]
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r16 = lane & 15, kq = lane >> 4;
-    const int br = r16 >> 3, bc = r16 & 7;
-
-    const int tiles_x = p.W / TW, tiles_y = (p.H + TH - 1) / TH, n_co = p.Cout / NCO;
-    const int n_tiles = tiles_x * tiles_y * p.B * n_co;
-    const int CB = p.cb_per_tap;
-    // this workgroup's tile range (XCD-contiguous logical id: one XCD's L2 sees neighbouring tiles and one weight slice)
-    const int L = xcd_contiguous_block(blockIdx.x, gridDim.x);
-    const int t_begin = (int)((long long)L * n_tiles / gridDim.x), t_end = (int)((long long)(L + 1) * n_tiles / gridDim.x);
-    if (t_begin >= t_end) return;
-
-    const __amdgpu_buffer_rsrc_t xr = make_rsrc(p.x, p.x_bytes);
-    const __amdgpu_buffer_rsrc_t skr = make_rsrc(IN == 2 && p.in_skip != nullptr ? p.in_skip : p.x, p.x_bytes);
-    const int hl = p.H >> 1, wlo = p.W >> 1;
-
-    // ---- tile coordinates: `c*` = the tile being computed, `n*` = the tile whose stages are being loaded --------------------
-    struct Tile { int co_tile, tx, ty, b; };
-    auto decode = [&](int t) {
-        Tile r;
-        r.co_tile = t % n_co; t /= n_co;
-        r.tx = t % tiles_x; t /= tiles_x;
-        r.ty = t % tiles_y;
-        r.b = t / tiles_y;
-        return r;
-    };
-    auto advance = [&](Tile& r) {
-        if (++r.co_tile == n_co) { r.co_tile = 0; if (++r.tx == tiles_x) { r.tx = 0; if (++r.ty == tiles_y) { r.ty = 0; ++r.b; } } }
-    };
-    Tile ct = decode(t_begin), nt = ct;
-    int n_tile = t_begin, n_cb = 0;                             // loader position (tile, stage)
-    bool n_ok = true;
-
-    // per-thread patch load offsets of the loader's tile
-    constexpr int PPT = (PQ + 255) / 256;
-    constexpr int LPT = (LQ + 255) / 256;
-    constexpr int NRP = IN == 2 ? LPT : PPT;
-    constexpr uint32_t OOB = 0x80000000u;
-    uint32_t poff[NRP];
-    f32x4 rp[NRP], rs[IN == 2 ? LPT : 1], sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    auto set_poff = [&](const Tile& tl) {
-        const int x0 = tl.tx * TW, y0 = tl.ty * TH;
-        if (IN != 2) {
-#pragma unroll
-            for (int u = 0; u < PPT; ++u) {
-                const int q = tid + 256 * u;
-                const int quad = q & 3, pix = q >> 2;
-                const int py = pix / PWID, px = pix - py * PWID;
-                const int iy = y0 - 1 + py, ix = x0 - 1 + px;
-                const bool ok = (q < PQ) & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
-                poff[u] = ok ? (uint32_t)(((tl.b * p.H + iy) * p.W + ix) * p.Cs + quad * 4) * 4u : OOB;
-            }
-        } else {
-#pragma unroll
-            for (int u = 0; u < LPT; ++u) {
-                const int q = tid + 256 * u;
-                const int quad = q & 3, pix = q >> 2;
-                const int r = pix / LW, c = pix - r * LW;
-                const int ly = min(max((y0 >> 1) - 1 + r, 0), hl - 1), lx = min(max((x0 >> 1) - 1 + c, 0), wlo - 1);
-                poff[u] = q < LQ ? (uint32_t)(((tl.b * hl + ly) * wlo + lx) * p.Cs + quad * 4) * 4u : OOB;
-            }
-        }
-    };
-    // global loads of the loader's stage: patch quads (or low-res quads) -> registers
-    auto patch_load = [&]() {
-        if (IN != 0 && p.in_affine != nullptr) {
-            const float* ap = p.in_affine + (((size_t)nt.b * (p.Cs >> 2) + (tid & 3)) * 2) * 4 + n_cb * 32;
-            sc = *reinterpret_cast<const f32x4*>(ap);
-            sh = *reinterpret_cast<const f32x4*>(ap + 4);
-        }
-        const uint32_t cbo = (uint32_t)n_cb * 64u;
-#pragma unroll
-        for (int u = 0; u < NRP; ++u) {
-            rp[u] = buf_load4(xr, poff[u] + cbo);
-            if (IN == 2 && p.in_skip != nullptr) rs[u] = buf_load4(skr, poff[u] + cbo);
-        }
-    };
-    // LDS-DMA of one slab half of the loader's stage.  A wave instruction fills 64 consecutive quads = 16 output channels of one tap;
-    // lane -> (co = lane >> 2, slot = lane & 3) and the slot holds source quad (slot - (co >> 1)) & 3 (the read-side rotation).
-    constexpr int DPW = HQ / 64 / 4;                            // DMA instructions per wave per half (2 * FCO)
-    const uint32_t dma_lane = (uint32_t)(((lane >> 2) * 16 + (((lane & 3) - ((lane >> 2) >> 1)) & 3) * 4) * 4);   // bytes inside a 1 KiB fragment
-    auto slab_dma = [&](int half) {
-        const char* src = reinterpret_cast<const char*>(p.wp);
-#pragma unroll
-        for (int u = 0; u < DPW; ++u) {
-            const int frag = wave * DPW + u;                    // 16-channel fragment inside the half: [8 taps][FCO]
-            const int tap = half * 8 + frag / FCO, cf = frag % FCO;
-            const size_t off = ((size_t)((n_cb * 16 + tap) * p.Cout + nt.co_tile * NCO + cf * 16) * 16) * 4;     // wavefront-uniform
-            __builtin_amdgcn_global_load_lds((gptr_t)(src + off + dma_lane), (lptr_t)(wl + half * HQ + frag * 64), 16, 0, 0);
-        }
-    };
-    auto patch_store = [&](int buf) {                          // IN != 2: registers -> patch copy `buf`
-        f32x4* pd = pt0 + buf * PREG;
-        const int x0 = nt.tx * TW, y0 = nt.ty * TH;
-#pragma unroll
-        for (int u = 0; u < PPT; ++u) {
-            const int q = tid + 256 * u;
-            const int pix = q >> 2, py = pix / PWID, px = pix - py * PWID;
-            f32x4 v = rp[IN == 2 ? 0 : u];
-            if (IN == 1) {
-                const int iy = y0 - 1 + py, ix = x0 - 1 + px;
-                const bool ok = ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
-                v = ok ? v * sc + sh : f32x4{0.f, 0.f, 0.f, 0.f};
-            }
-            if (q < PQ) pd[py * SY + pslot(px, q & 3)] = v;
-        }
-    };
-    auto l_store = [&]() {                                     // IN == 2: transformed low-res quads -> L region
-#pragma unroll
-        for (int u = 0; u < LPT; ++u) {
-            const int q = tid + 256 * u;
-            f32x4 v = rp[u];
-            if (p.in_affine != nullptr) v = v * sc + sh;
-            if (p.in_skip != nullptr) v += rs[u];
-            if (p.in_act == SBGM_ACT_SILU) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = v[e] * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v[e]));
-            } else if (p.in_act != SBGM_ACT_NONE) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = sbgm_act(v[e], p.in_act);
-            }
-            if (q < LQ) lr0[q] = v;
-        }
-    };
-    constexpr int PQ2 = PH * 8 * 4;
-    constexpr int PPT2 = (PQ2 + 255) / 256;
-    auto expand = [&](const Tile& tl) {                        // IN == 2: L region -> W patch (column-transformed upsampled rows)
-        const int x0 = tl.tx * TW, y0 = tl.ty * TH;
-#pragma unroll
-        for (int u = 0; u < PPT2; ++u) {
-            const int q = tid + 256 * u;
-            const int quad = q & 3, pair = (q >> 2) & 7, py = q >> 5;
-            const int iy = y0 - 1 + py;
-            const int ra = py >> 1;
-            const float wya = (py & 1) ? (iy == 0 ? 0.f : 0.25f) : 0.75f, wyb = 1.f - wya;
-            if (q < PQ2) {
-                const f32x4* la = lr0 + (ra * LW + pair) * 4 + quad;
-                const f32x4* lb = la + LW * 4;
-                f32x4 xa = wya * la[0] + wyb * lb[0], xb = wya * la[4] + wyb * lb[4], xc = wya * la[8] + wyb * lb[8];
-                if ((unsigned)iy >= (unsigned)p.H) xa = xb = xc = f32x4{0.f, 0.f, 0.f, 0.f};
-                const bool zl = x0 == 0 && pair == 0, zr = x0 + TW == p.W && pair == 7;
-                const float a0 = zl ? 0.f : 0.75f, b0 = zl ? -0.75f : -0.5f, b3 = zr ? 0.75f : 0.5f, c3 = zr ? 0.f : -0.75f;
-                f32x4* o = pt0 + ((py * 4) * 8 + pair) * 4 + ((quad + 2 * ((py >> 1) & 1)) & 3);
-                o[0] = a0 * xa + b0 * xb - 0.25f * xc;
-                o[32] = 0.25f * (xa + xc) + 1.5f * xb;
-                o[64] = 0.25f * (xc - xa);
-                o[96] = 0.25f * xa + b3 * xb + c3 * xc;
-            }
-        }
-    };
-    auto loader_next = [&]() {                                 // loader -> next stage (possibly of the next tile)
-        if (++n_cb == CB) {
-            n_cb = 0;
-            ++n_tile;
-            n_ok = n_tile < t_end;
-            if (n_ok) { advance(nt); set_poff(nt); }
-        }
-    };
-
-    // ---- loop-invariant LDS read offsets of this lane (quads) -------------------------------------------------------------
-    const int aoff = wslot(r16, kq);
-    const int r0 = wave * 4 + 2 * br;
-    int coff[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) coff[c] = IN == 2 ? (c * 8 + bc) * 4 : pslot(2 * bc + c, kq);
-
-    f32x4 acc[16][FCO];
-#pragma unroll
-    for (int tp = 0; tp < 16; ++tp)
-#pragma unroll
-        for (int i = 0; i < FCO; ++i) acc[tp][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    // ---- prologue: stage 0 of the first tile --------------------------------------------------------------------------------
-    set_poff(nt);
-    slab_dma(0);
-    slab_dma(1);
-    patch_load();
-    if (IN != 2) patch_store(0);
-    else l_store();
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (IN == 2) { expand(nt); }
-    loader_next();                                              // loader now at stage 1
-    if (n_ok) patch_load();                                     // registers <- patch(1)
-    if (IN == 2) __syncthreads();                               // W patch of stage 0 visible (its DMA halves were drained above)
-
-    int pbuf = 0;                                               // patch copy of the stage being swept (IN != 2)
-    for (int tile = t_begin; tile < t_end; ++tile) {
-        for (int cb = 0; cb < CB; ++cb) {
-            const f32x4* pt = pt0 + (IN == 2 ? 0 : pbuf * PREG);
-            auto ldrow = [&](int rr, int c) -> f32x4 {
-                if (IN == 2) return pt[(r0 + rr) * 128 + coff[c] + ((kq + 2 * (((r0 + rr) >> 1) & 1)) & 3)];
-                return pt[(r0 + rr) * SY + coff[c]];
-            };
-            constexpr int RA[4] = {0, 1, 2, 1}, RB[4] = {2, 2, 1, 3};     // B^T rows: d0 - d2, d1 + d2, d2 - d1, d1 - d3
-            // one half of the sweep: xi = 2*half, 2*half + 1.  The A fragments of the next (xi, eta) group and the patch rows of the
-            // next xi are requested one group ahead of the MFMAs that consume them.
-            auto sweep_half = [&](int half) {
-                f32x4 a_cur[FCO], a_nxt[FCO], V[4], Vn[4], da[4], db[4];
-                const int g0 = half * 8;
-#pragma unroll
-                for (int i = 0; i < FCO; ++i) a_cur[i] = wl[(g0 * NCO + 16 * i) * 4 + aoff];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) { da[c] = ldrow(RA[2 * half], c); db[c] = ldrow(RB[2 * half], c); }
-#pragma unroll
-                for (int c = 0; c < 4; ++c) da[c] = da[c] - db[c];         // xi = 0 and xi = 2 both subtract
-                if (IN == 2) {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c) V[c] = da[c];
-                } else {
-                    V[0] = da[0] - da[2]; V[1] = da[1] + da[2]; V[2] = da[2] - da[1]; V[3] = da[1] - da[3];
-                }
-#pragma unroll
-                for (int gg = 0; gg < 8; ++gg) {
-                    const int g = g0 + gg, xi = g >> 2, eta = g & 3;
-                    const bool more = gg < 4;                               // a second xi follows inside this half
-                    // requests first, pinned above this group's MFMAs (left alone the scheduler sinks them to one MFMA before use)
-                    if (gg + 1 < 8) {
-#pragma unroll
-                        for (int i = 0; i < FCO; ++i) a_nxt[i] = wl[((g + 1) * NCO + 16 * i) * 4 + aoff];
-                    }
-                    if (eta == 0 && more) {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) { da[c] = ldrow(RA[xi + 1], c); db[c] = ldrow(RB[xi + 1], c); }
-                    }
-                    if (eta == 2 && more) {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) da[c] = xi + 1 == 1 ? da[c] + db[c] : da[c] - db[c];
-                    }
-                    if (eta == 3 && more) {
-                        if (IN == 2) {
-#pragma unroll
-                            for (int c = 0; c < 4; ++c) Vn[c] = da[c];
-                        } else {
-                            Vn[0] = da[0] - da[2]; Vn[1] = da[1] + da[2]; Vn[2] = da[2] - da[1]; Vn[3] = da[1] - da[3];
-                        }
-                    }
-#pragma unroll
-                    for (int k = 0; k < 4; ++k)
-#pragma unroll
-                        for (int i = 0; i < FCO; ++i)
-                            acc[g][i] = __builtin_amdgcn_mfma_f32_16x16x4f32(a_cur[i][k], V[eta][k], acc[g][i], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int i = 0; i < FCO; ++i) a_cur[i] = a_nxt[i];
-                    if (eta == 3 && more) {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c) V[c] = Vn[c];
-                    }
-                }
-            };
-
-            sweep_half(0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // this wave's DMA of H1(s) (and the patch registers) have landed
-            __syncthreads();                                    // M: H0 is free, H1 of this stage has landed
-            if (n_ok) slab_dma(0);                              // H0 of the next stage
-            if (IN == 2) { if (n_ok) l_store(); }               // L region: last read by this stage's expand, before E
-            sweep_half(1);
-            if (IN != 2 && n_ok) patch_store(pbuf ^ 1);
-
-            // The DMA of H0(s+1) and the patch registers must have landed before E; waiting for them HERE, before the epilogue's stores
-            // are issued, keeps those stores out of the wait (vmcnt retires in order: a vmcnt(0) behind 8 stores per lane waits for
-            // their write acknowledgements, measured 12 k cycles per tile)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (cb == CB - 1) {
-                // ---- per-tile epilogue: Y = A^T M A, the shared convolution epilogue on the block's 4 pixels --------------------
-                const int co0 = ct.co_tile * NCO, x0 = ct.tx * TW, y0 = ct.ty * TH, b = ct.b;
-                const bool want_stats = p.gn_stats != nullptr;
-                f32x4 gs[FCO], gs2[FCO];
-#pragma unroll
-                for (int i = 0; i < FCO; ++i) { gs[i] = f32x4{0.f, 0.f, 0.f, 0.f}; gs2[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-                const int oy = y0 + wave * 4 + 2 * br, ox = x0 + 2 * bc;
-                const bool ok = oy < p.H;
-                const int m00 = (b * p.H + (ok ? oy : 0)) * p.W + ox;
-                f32x4 y[4][FCO];
-#pragma unroll
-                for (int i = 0; i < FCO; ++i) {
-                    f32x4 P0[4], P1[4];
-#pragma unroll
-                    for (int xi = 0; xi < 4; ++xi) {
-                        P0[xi] = acc[xi * 4][i] + acc[xi * 4 + 1][i] + acc[xi * 4 + 2][i];
-                        P1[xi] = acc[xi * 4 + 1][i] - acc[xi * 4 + 2][i] - acc[xi * 4 + 3][i];
-                    }
-#pragma unroll
-                    for (int tp = 0; tp < 16; ++tp) acc[tp][i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                    const int co = co0 + 16 * i + 4 * kq;
-                    y[0][i] = conv_epilogue(P0[0] + P0[1] + P0[2], p, co, (size_t)m00, b);
-                    y[1][i] = conv_epilogue(P1[0] + P1[1] + P1[2], p, co, (size_t)m00 + 1, b);
-                    y[2][i] = conv_epilogue(P0[1] - P0[2] - P0[3], p, co, (size_t)m00 + p.W, b);
-                    y[3][i] = conv_epilogue(P1[1] - P1[2] - P1[3], p, co, (size_t)m00 + p.W + 1, b);
-                    if (!PROJ && ok) {
-                        float* o = p.out + (size_t)m00 * p.Cout + co;
-                        *reinterpret_cast<f32x4*>(o) = y[0][i];
-                        *reinterpret_cast<f32x4*>(o + p.Cout) = y[1][i];
-                        *reinterpret_cast<f32x4*>(o + (size_t)p.W * p.Cout) = y[2][i];
-                        *reinterpret_cast<f32x4*>(o + (size_t)(p.W + 1) * p.Cout) = y[3][i];
-                        if (want_stats) {
-                            gs[i] += (y[0][i] + y[1][i]) + (y[2][i] + y[3][i]);
-                            gs2[i] += (y[0][i] * y[0][i] + y[1][i] * y[1][i]) + (y[2][i] * y[2][i] + y[3][i] * y[3][i]);
-                        }
-                    }
-                }
-                if (PROJ) {
-                    const float* wlp = p.proj_w + co0 + 4 * kq;
-                    float* po = p.proj_out + (size_t)ct.co_tile * 9 * p.M;
-#pragma unroll
-                    for (int tap = 0; tap < 9; ++tap) {
-                        float s[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                        for (int i = 0; i < FCO; ++i) {
-                            const f32x4 w4 = *reinterpret_cast<const f32x4*>(wlp + tap * p.Cout + 16 * i);
-#pragma unroll
-                            for (int px = 0; px < 4; ++px)
-#pragma unroll
-                                for (int e = 0; e < 4; ++e) s[px] = fmaf(y[px][i][e], w4[e], s[px]);
-                        }
-#pragma unroll
-                        for (int px = 0; px < 4; ++px) {
-                            s[px] += __shfl_xor(s[px], 16, 64);
-                            s[px] += __shfl_xor(s[px], 32, 64);
-                        }
-                        if (ok && kq == (tap & 3)) {
-                            float* o = po + (size_t)tap * p.M + m00;
-                            o[0] = s[0]; o[1] = s[1]; o[p.W] = s[2]; o[p.W + 1] = s[3];
-                        }
-                    }
-                }
-                if (want_stats) {
-                    // GroupNorm statistics of this tile, deterministic: lanes by shuffles, waves through LDS (own scratch region: the
-                    // stage buffers are live), groups in fp64; the two barriers are uniform (every wave runs the same stage)
-#pragma unroll
-                    for (int i = 0; i < FCO; ++i)
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-#pragma unroll
-                            for (int o = 1; o < 16; o <<= 1) {
-                                gs[i][e] += __shfl_xor(gs[i][e], o, 64);
-                                gs2[i][e] += __shfl_xor(gs2[i][e], o, 64);
-                            }
-                    if (r16 == 0) {
-#pragma unroll
-                        for (int i = 0; i < FCO; ++i)
-#pragma unroll
-                            for (int e = 0; e < 4; ++e) {
-                                red[((wave * NCO) + 16 * i + 4 * kq + e) * 2] = gs[i][e];
-                                red[((wave * NCO) + 16 * i + 4 * kq + e) * 2 + 1] = gs2[i][e];
-                            }
-                    }
-                    __syncthreads();
-                    const int G = p.gn_groups, cpg = p.Cout / G;
-                    const int sub = cpg > NCO ? cpg / NCO : 1;
-                    const int ngrp = cpg > NCO ? 1 : NCO / cpg;
-                    const int span = cpg > NCO ? NCO : cpg;
-                    if (tid < ngrp) {
-                        double a = 0.0, a2 = 0.0;
-                        for (int c = tid * span; c < (tid + 1) * span; ++c)
-                            for (int w = 0; w < 4; ++w) {
-                                a += (double)red[(w * NCO + c) * 2];
-                                a2 += (double)red[(w * NCO + c) * 2 + 1];
-                            }
-                        const int chunks = tiles_x * tiles_y * sub;
-                        const int chunk = (ct.ty * tiles_x + ct.tx) * sub + (ct.co_tile % sub);
-                        const int g = co0 / cpg + tid;
-                        double* o = p.gn_stats + (((size_t)b * chunks + chunk) * G + g) * 2;
-                        o[0] = a;
-                        o[1] = a2;
-                    }
-                    __syncthreads();                            // `red` is reused by the next tile
-                }
-                advance(ct);
-            }
-            __syncthreads();                                    // E: every wave is done with this stage; H0 of the next has landed
-            if (n_ok) {
-                slab_dma(1);                                    // H1 of the next stage
-                if (IN == 2) {
-                    expand(nt);                                 // L region (stored after M) -> W patch of the next stage
-                }
-            }
-            const bool had = n_ok;
-            loader_next();
-            if (n_ok) patch_load();                             // registers <- patch of the stage after next
-            if (IN == 2) { if (had) __syncthreads(); }          // X: W patch visible
-            else pbuf ^= 1;
-        }
-    }
-}
-
-
 // OIHW [Cout][Cin][3][3] -> U[cb][xi*4 + eta][Cout][16],  U = G g G^T  (rows first, then columns; G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1])
 __global__ void pack_w2d_weight_kernel(const float* __restrict__ w, float* __restrict__ up, int Cout, int Cin, int cs) {
     const int CB = cs / 16;
@@ -882,11 +549,6 @@ int sbgm_conv_w2d_gn_chunks(const ConvParams& p, const ConvTile& cfg) {
 }
 
 size_t sbgm_conv_w2d_bytes(const ConvTile& cfg, int in_mode) {
-    if (cfg.lds == 3) {                          // persistent kernel: slab + two patch copies (mode 2: one + low-res region) + statistics scratch
-        const size_t quads = (size_t)16 * 16 * cfg.fco * 4 +
-                             (in_mode == 2 ? (size_t)PH * 128 + (size_t)(TH / 2 + 2) * (TW / 2 + 2) * 4 : (size_t)2 * PH * SY);
-        return quads * 16 + (size_t)4 * 16 * cfg.fco * 2 * 4;
-    }
     const int nbuf = cfg.lds == 2 ? 2 : 1;
     size_t quads = ((size_t)16 * 16 * cfg.fco * 4 + (in_mode == 2 ? (size_t)PH * 128 : (size_t)PH * SY)) * nbuf;
     if (in_mode == 2) quads += (size_t)(TH / 2 + 2) * (TW / 2 + 2) * 4 * nbuf;
@@ -896,19 +558,7 @@ size_t sbgm_conv_w2d_bytes(const ConvTile& cfg, int in_mode) {
 // number of co tiles a projection launch writes partial planes for (the tap_stencil launch sums them)
 int sbgm_conv_w2d_proj_parts(const ConvParams& p, const ConvTile& cfg) { return p.Cout / (16 * cfg.fco); }
 
-static int w2d_cus() {
-    static int n = 0;
-    if (!n) {
-        int dev = 0;
-        hipDeviceProp_t pr;
-        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess) n = pr.multiProcessorCount;
-        if (n <= 0) n = 256;
-    }
-    return n;
-}
-
-// cfg.wino == 2; cfg.fco in {1, 2}; cfg.lds 1 (single stage buffer), 2 (double-buffered) or 3 (persistent kernel); p.wp = the
-// F(2x2,3x3) weight image.
+// cfg.wino == 2; cfg.fco in {1, 2}; cfg.lds 1 (single stage buffer) or 2 (double-buffered); p.wp = the F(2x2,3x3) weight image.
 int sbgm_launch_conv_w2d(ConvParams p, const ConvTile& cfg, hipStream_t st) {
     SBGM_CHECK(p.Cs % 16 == 0 && p.W % 16 == 0 && p.H % 2 == 0, "conv_w2d: needs Cin padded to 16, W %% 16 == 0 and an even H (Cs=%d H=%d W=%d)", p.Cs, p.H, p.W);
     SBGM_CHECK(p.Cout % (16 * cfg.fco) == 0, "conv_w2d: Cout=%d not a multiple of the %d-channel tile", p.Cout, 16 * cfg.fco);
@@ -930,25 +580,7 @@ int sbgm_launch_conv_w2d(ConvParams p, const ConvTile& cfg, hipStream_t st) {
     const size_t lds = sbgm_conv_w2d_bytes(cfg, p.in_mode);
     SBGM_CHECK(lds <= 160 * 1024, "conv_w2d: tile needs %zu bytes of LDS", lds);
     int rc = 1;
-    if (cfg.lds == 3) {                          // persistent workgroups: cfg.ws = workgroups per CU the grid is sized for (0 -> 2)
-        const int per_cu = cfg.ws >= 1 && cfg.ws <= 8 ? cfg.ws : 2;
-        const int grid = std::min(tiles, per_cu * w2d_cus());
-        const bool proj = p.proj_w != nullptr;
-#define SBGM_P3(FC, INV, PJ)                                                                                  \
-    if (cfg.fco == FC && p.in_mode == INV && proj == PJ) {                                                    \
-        if (lds > 64 * 1024)                                                                                  \
-            SBGM_HIP(hipFuncSetAttribute((const void*)conv3x3_w2dp_kernel<FC, INV, PJ>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
-        hipLaunchKernelGGL((conv3x3_w2dp_kernel<FC, INV, PJ>), dim3(grid), dim3(256), lds, st, p);           \
-        rc = 0;                                                                                              \
-    }
-        SBGM_P3(1, 0, false) SBGM_P3(1, 1, false) SBGM_P3(1, 2, false) SBGM_P3(2, 0, false) SBGM_P3(2, 1, false) SBGM_P3(2, 2, false)
-        SBGM_P3(1, 0, true) SBGM_P3(1, 1, true) SBGM_P3(1, 2, true) SBGM_P3(2, 0, true) SBGM_P3(2, 1, true) SBGM_P3(2, 2, true)
-#undef SBGM_P3
-        SBGM_CHECK(rc == 0, "conv_w2d: no persistent kernel for tile fco=%d in_mode=%d", cfg.fco, p.in_mode);
-        SBGM_LAUNCH_CHECK();
-        return 0;
-    }
-    const int minw = cfg.ws == 2 ? 2 : 1;
+    const int minw = cfg.ws;
 #define SBGM_L3(FC, MW, DBV, INV)                                                                             \
     if (cfg.fco == FC && minw == MW && db == DBV && p.in_mode == INV) {                                       \
         if (lds > 64 * 1024)                                                                                  \
@@ -957,7 +589,7 @@ int sbgm_launch_conv_w2d(ConvParams p, const ConvTile& cfg, hipStream_t st) {
         rc = 0;                                                                                              \
     }
 #define SBGM_L(FC, MW) SBGM_L3(FC, MW, false, 0) SBGM_L3(FC, MW, true, 0) SBGM_L3(FC, MW, false, 1) SBGM_L3(FC, MW, true, 1) SBGM_L3(FC, MW, false, 2) SBGM_L3(FC, MW, true, 2)
-    SBGM_L(1, 1) SBGM_L(2, 1) SBGM_L(2, 2)
+    SBGM_L(1, 1) SBGM_L(2, 1) SBGM_L(2, 2) SBGM_L(1, 3) SBGM_L(1, 2)
 #undef SBGM_L
 #undef SBGM_L3
     SBGM_CHECK(rc == 0, "conv_w2d: no kernel for tile fco=%d ws=%d lds=%d in_mode=%d", cfg.fco, cfg.ws, cfg.lds, p.in_mode);
