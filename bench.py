@@ -262,9 +262,15 @@ def train_bench(a):
         loss.backward()
         return loss
 
+    if bucket is not None:
+        opt.grad_scale = 1.0 / world               # the averaging rides on the Adam launch: the bucket keeps the SUM
+        if not graphed:                            # eager steps: the decoder slice is all-reduced from inside backward (overlap)
+            from sbgm_danra_amd.train_graph import set_overlap_bucket
+            set_overlap_bucket(bucket)
+
     def finish():
         if bucket is not None:
-            bucket.all_reduce_()
+            bucket.all_reduce_(average=False)
         opt.step()
 
     if graphed:

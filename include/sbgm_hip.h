@@ -342,8 +342,10 @@ typedef struct sbgm_adam_desc {
     int block_begin, reserved;
 } sbgm_adam_desc;
 int sbgm_adam_step_blocks(int64_t numel);
+/* grad_scale multiplies every gradient as it is read (1, or 1/world when the gradients are the data-parallel SUM over the
+ * replicas: the averaging of reference-style data parallelism without a pass of its own). */
 int sbgm_adam_step_batched(const sbgm_adam_desc* desc_dev, int n, int total_blocks, const float* step, float lr, float beta1,
-                           float beta2, float eps, float weight_decay, int decoupled, void* stream);
+                           float beta2, float eps, float weight_decay, int decoupled, float grad_scale, void* stream);
 int sbgm_colsum(const float* x, const float* y /* NULL or multiplied elementwise */, float* out, int M, int C, void* stream);
 int sbgm_samplesum(const float* x, float* out /* [B,C] */, int B, int HW, int C, void* stream);
 /* ws: >= 8*B*C bytes */

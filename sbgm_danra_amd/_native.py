@@ -105,7 +105,7 @@ SIGNATURES = {
     "sbgm_conv_pack_weights_batched": (_i, [_vp, _i, _i, _vp]),
     "sbgm_conv_pack_weights_batched_blocks": (_i, [_i, _i, _i, _i]),
     "sbgm_adam_step_blocks": (_i, [C.c_int64]),
-    "sbgm_adam_step_batched": (_i, [_vp, _i, _i, _vp, _f, _f, _f, _f, _f, _i, _vp]),
+    "sbgm_adam_step_batched": (_i, [_vp, _i, _i, _vp, _f, _f, _f, _f, _f, _i, _f, _vp]),
     "sbgm_set_scratch_prezeroed": (_i, [_i]),
     "sbgm_conv_wino_packed_numel": (_i64, [_i, _i]),
     "sbgm_conv_wino_pack_weight": (_i, [_vp, _vp, _i, _i, _i, _vp]),

@@ -84,8 +84,8 @@ int sbgm_conv_pack_weights_batched(const sbgm_pack_desc* desc_dev, int n, int to
 }                                                                                    // guarantees bit 1 only on 3x3, cs%16, Cout%16
 int sbgm_adam_step_blocks(int64_t numel) { return sbgm_adam_blocks(numel); }
 int sbgm_adam_step_batched(const sbgm_adam_desc* desc_dev, int n, int total_blocks, const float* step, float lr, float beta1,
-                           float beta2, float eps, float weight_decay, int decoupled, void* stream) {
-    return sbgm_launch_adam_batched(desc_dev, n, total_blocks, step, lr, beta1, beta2, eps, weight_decay, decoupled, ST);
+                           float beta2, float eps, float weight_decay, int decoupled, float grad_scale, void* stream) {
+    return sbgm_launch_adam_batched(desc_dev, n, total_blocks, step, lr, beta1, beta2, eps, weight_decay, decoupled, grad_scale, ST);
 }
 int sbgm_batchnorm_train_stats(const float* x, int B, int HW, int C, void* stats_ws, void* stream) {
     return sbgm_launch_batchnorm_stats(x, B, HW, C, static_cast<double*>(stats_ws), ST);

@@ -58,7 +58,7 @@ struct sbgm_pack_desc;
 struct sbgm_adam_desc;
 int sbgm_adam_blocks(int64_t numel);
 int sbgm_launch_adam_batched(const sbgm_adam_desc* desc_dev, int n, int total_blocks, const float* step_dev, float lr, float beta1,
-                             float beta2, float eps, float weight_decay, int decoupled, hipStream_t st);
+                             float beta2, float eps, float weight_decay, int decoupled, float grad_scale, hipStream_t st);
 int sbgm_launch_pack_conv_weights_batched(const sbgm_pack_desc* desc_dev, int n, int total_blocks, hipStream_t st);
 int sbgm_launch_conv(const ConvGeom& g, ConvParams p, const ConvTile& cfg, float* partial_ws, hipStream_t st);
 // When set, the launchers below trust that their atomically accumulated scratch (weight-gradient slab, norm-backward sums)

@@ -4,7 +4,9 @@
 // K40 adam_batched_kernel — descriptor table (param, grad, exp_avg, exp_avg_sq, numel) on the device, one workgroup per
 //     1024 elements, the tensor found by binary search over the block prefix (as the batched weight pack does).  The update
 //     is torch's (torch/optim/adam.py, single-tensor form; the same expressions as its fused CUDA kernel):
-//         g'      = g + wd * p                      (Adam: L2 term)        |  p *= 1 - lr * wd   (AdamW: decoupled)
+//         g'      = s * g + wd * p                  (Adam: L2 term)        |  p *= 1 - lr * wd   (AdamW: decoupled)
+//                   s = grad_scale: 1, or 1 / world when g is the data-parallel SUM of the replicas' gradients (the division of
+//                   reference-style averaging rides on this launch instead of a 76 MB read + write pass of its own)
 //         m       = m + (1 - b1) * (g' - m)
 //         v       = b2 * v + (1 - b2) * g' * g'
 //         p      -= (lr / (1 - b1^t)) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
@@ -21,7 +23,7 @@ namespace {
 constexpr int ADAM_BLOCK_ELEMS = 1024;
 
 __global__ __launch_bounds__(256) void adam_batched_kernel(const sbgm_adam_desc* __restrict__ desc, int n, const float* __restrict__ step,
-                                                           float lr, float beta1, float beta2, float eps, float wd, int decoupled) {
+                                                           float lr, float beta1, float beta2, float eps, float wd, int decoupled, float gscale) {
     int lo = 0, hi = n - 1;                                  // last descriptor whose first block is <= blockIdx.x
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
@@ -34,6 +36,7 @@ __global__ __launch_bounds__(256) void adam_batched_kernel(const sbgm_adam_desc*
     const int64_t i0 = (int64_t)(blockIdx.x - d.block_begin) * ADAM_BLOCK_ELEMS + threadIdx.x * 4;
     if (i0 >= d.numel) return;
     auto update = [&](float& p, float g, float& m, float& v) {
+        g *= gscale;
         if (wd != 0.f) {
             if (decoupled) p *= 1.f - lr * wd; else g += wd * p;
         }
@@ -65,12 +68,12 @@ __global__ __launch_bounds__(256) void adam_batched_kernel(const sbgm_adam_desc*
 int sbgm_adam_blocks(int64_t numel) { return (int)((numel + ADAM_BLOCK_ELEMS - 1) / ADAM_BLOCK_ELEMS); }
 
 int sbgm_launch_adam_batched(const sbgm_adam_desc* desc_dev, int n, int total_blocks, const float* step_dev, float lr, float beta1,
-                             float beta2, float eps, float weight_decay, int decoupled, hipStream_t st) {
+                             float beta2, float eps, float weight_decay, int decoupled, float grad_scale, hipStream_t st) {
     SBGM_CHECK(desc_dev && step_dev && n >= 1 && total_blocks >= 1, "adam_step_batched: bad arguments");
     SBGM_CHECK(beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps >= 0.f, "adam_step_batched: betas (%g, %g) / eps %g", beta1,
                beta2, eps);
     hipLaunchKernelGGL(adam_batched_kernel, dim3(total_blocks), dim3(256), 0, st, desc_dev, n, step_dev, lr, beta1, beta2, eps, weight_decay,
-                       decoupled);
+                       decoupled, grad_scale);
     SBGM_LAUNCH_CHECK();
     return 0;
 }

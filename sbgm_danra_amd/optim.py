@@ -13,8 +13,13 @@ from . import _native as N
 
 
 class _NativeStep:
-    """mix-in: the per-group descriptor table and the launch"""
+    """mix-in: the per-group descriptor table and the launch.
+
+    `grad_scale` (default 1.0) multiplies every gradient as the step reads it.  The data-parallel pipeline sets it to 1 / world
+    and leaves the all-reduced SUM in `.grad`: the division of gradient averaging then costs nothing (a `flat.div_(world)` is a
+    76 MB read + write pass per step).  Groups that fall back to torch's own step get their gradients scaled in place first."""
     _decoupled = 0
+    grad_scale = 1.0
 
     def _native_ok(self, group, params):
         return (params and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() and not p.grad.is_sparse
@@ -43,6 +48,9 @@ class _NativeStep:
                 for g, ps in saved:
                     keep = [p for p in ps if p.grad is not None]
                     g["params"] = [] if (keep and self._native_ok(g, keep)) else ps
+                    if g["params"] and self.grad_scale != 1.0:
+                        for p in keep:
+                            p.grad.mul_(self.grad_scale)
                 super().step()
             finally:
                 for g, ps in saved:
@@ -85,7 +93,7 @@ class _NativeStep:
         master += 1
         b1, b2 = group["betas"]
         N.check(N.lib().sbgm_adam_step_batched(tab[1].data_ptr(), tab[2], tab[3], master.data_ptr(), float(group["lr"]), float(b1), float(b2),
-                                               float(group["eps"]), float(group["weight_decay"]), self._decoupled, N.stream()))
+                                               float(group["eps"]), float(group["weight_decay"]), self._decoupled, float(self.grad_scale), N.stream()))
         N.bump_generation()                            # parameters were written through raw pointers (no version-counter bump)
 
 

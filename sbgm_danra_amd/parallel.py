@@ -56,14 +56,23 @@ def shard_range(n_items: int, rank: int, world_size: int) -> range:
 
 
 class GradientBucket:
-    """One flat fp32 gradient tensor + one sum all-reduce, averaged over ranks.
+    """One flat fp32 gradient tensor, summed over the ranks in up to two all-reduces, the first overlapped with backward.
 
     `GradientBucket(model)` adopts the model's gradient ARENA (train_graph.GradArena): the native backward kernels write every
     parameter gradient straight into its slice and `p.grad` is a view of it, so the exchange is the all-reduce alone — no
     gather / scatter copies (the native Adam step reads the same memory through `p.grad`).  A gradient that did not land in the
     arena (live `.grad` tensors from gradient accumulation, the ConvTranspose2d ablation weights, a CPU model) is copied in and
     `p.grad` re-pointed at its slice, which keeps the result identical.
-    `GradientBucket(iterable of parameters)` (no arena) keeps the same interface with a private flat tensor."""
+    `GradientBucket(iterable of parameters)` (no arena) keeps the same interface with a private flat tensor.
+
+    Overlap.  The arena is in parameter order: encoder | decoder.  Backward runs the decoder first, so when the gradient reaches the
+    encoder/decoder boundary (train_graph._BucketBoundary on the bottleneck feature map) every decoder gradient is final:
+    `begin_early(params)` then starts an ASYNCHRONOUS all-reduce of the decoder slice (5.4 M of the 19 M parameters) that runs
+    beside the encoder's backward; `all_reduce_()` after backward waits for it and reduces the rest.  Summation is per element
+    in both forms, so the result is bit-identical to the single all-reduce (world size 2: a + b either way).
+
+    average=True divides by the world size in place (a read + write pass over the bucket); the training pipeline passes False
+    and sets `optimizer.grad_scale = 1 / world` instead (optim.Adam folds the factor into its launch)."""
 
     def __init__(self, model_or_params):
         self.model = model_or_params if isinstance(model_or_params, torch.nn.Module) else None
@@ -73,41 +82,81 @@ class GradientBucket:
             raise ValueError("GradientBucket needs at least one trainable parameter")
         self._own = None
         self.copies = 0                                 # gradients that had to be copied into the flat tensor (diagnostic)
+        self.early = 0                                  # asynchronous early all-reduces launched (diagnostic)
+        self._pending = None                            # (work handle, first element, end element) of the early slice
+        self._index = {id(p): i for i, p in enumerate(self.params)}
 
     def _layout(self):
-        """(flat tensor, [view per parameter])"""
+        """(flat tensor, [view per parameter], [offset per parameter])"""
         if self.model is not None and self.params[0].is_cuda:
             from .train_graph import arena_for
             arena = arena_for(self.model)
             if getattr(self, "_views_for", None) is not arena:
                 self._views = [arena.grad_of(p) for p in self.params]
+                self._offs = [arena.index[p.data_ptr()][0] for p in self.params]
                 self._views_for = arena
-            return arena.flat, self._views
+            return arena.flat, self._views, self._offs
         if self._own is None:
             dev = self.params[0].device
             flat = torch.zeros(sum(p.numel() for p in self.params), dtype=torch.float32, device=dev)
-            views, off = [], 0
+            views, offs, off = [], [], 0
             for p in self.params:
                 views.append(flat[off:off + p.numel()].view(p.shape))
+                offs.append(off)
                 off += p.numel()
-            self._own = (flat, views)
+            self._own = (flat, views, offs)
         return self._own
 
-    def all_reduce_(self) -> None:
-        rank, ws = world()
-        if ws == 1:
-            return
-        flat, views = self._layout()
-        for p, v in zip(self.params, views):
+    def _adopt(self, idxs, views, zero_missing=True):
+        for i in idxs:
+            p, v = self.params[i], views[i]
             g = p.grad
             if g is None:
-                v.zero_()                               # unused parameter: contributes 0, stays without a gradient
+                if zero_missing:
+                    v.zero_()                           # unused on this rank: contributes 0 (the reduced value is attached below)
             elif g.data_ptr() != v.data_ptr():
                 v.copy_(g)
                 p.grad = v
                 self.copies += 1
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-        flat.div_(ws)
+
+    def begin_early(self, params: Iterable[torch.nn.Parameter]) -> bool:
+        """Start the asynchronous all-reduce of the CONTIGUOUS tail slice holding `params` (their gradients must be final).
+        Returns False (and does nothing) with one rank, an early slice already in flight, or a slice that is not the tail."""
+        rank, ws = world()
+        if ws == 1 or self._pending is not None:
+            return False
+        idxs = sorted(self._index[id(p)] for p in params if id(p) in self._index)
+        if not idxs or idxs[-1] != len(self.params) - 1 or idxs != list(range(idxs[0], idxs[-1] + 1)):
+            return False
+        flat, views, offs = self._layout()
+        # mid-backward: a slice without a .grad yet is left alone (the arena was zeroed at the start of the step and the kernels write
+        # into it directly; zeroing here could wipe a gradient whose AccumulateGrad has not run)
+        self._adopt(idxs, views, zero_missing=self._own is not None)
+        a = offs[idxs[0]]
+        work = dist.all_reduce(flat[a:], op=dist.ReduceOp.SUM, async_op=True)
+        self._pending = (work, a, idxs[0])
+        self.early += 1
+        return True
+
+    def all_reduce_(self, average: bool = True) -> None:
+        rank, ws = world()
+        if ws == 1:
+            return
+        flat, views, offs = self._layout()
+        end, n_rest = flat.numel(), len(self.params)
+        if self._pending is not None:
+            work, end, n_rest = self._pending
+            self._pending = None
+        self._adopt(range(n_rest), views)
+        missing = [i for i, p in enumerate(self.params) if p.grad is None]
+        if end > 0:
+            dist.all_reduce(flat[:end], op=dist.ReduceOp.SUM)
+        if n_rest < len(self.params):
+            work.wait()
+        for i in missing:                               # no local gradient: every rank must still step this parameter alike
+            self.params[i].grad = views[i]
+        if average:
+            flat.div_(ws)
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0) -> None:
@@ -116,6 +165,9 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0) -> None:
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src)
+    if any(t.is_cuda for t in module.parameters()):
+        from . import _native                           # written through .data: no version bump an engine copy could see
+        _native.bump_generation()
 
 
 def sample_sharded(sampler, n_batches: int, make_kwargs, gather: bool = False):

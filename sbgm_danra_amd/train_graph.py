@@ -972,9 +972,38 @@ def decoder_block_forward(blk, cur, skip, t, tbd=None):
     return out
 
 
+# Data-parallel overlap (parallel.GradientBucket): backward runs the decoder before the encoder, so the moment the gradient of the
+# bottleneck feature map is delivered every decoder gradient is final.  An identity node there flushes the queued weight-gradient
+# layout passes and starts the asynchronous all-reduce of the decoder's slice of the arena; it then runs beside the encoder's backward.
+_OVERLAP_BUCKET = [None]
+
+
+def set_overlap_bucket(bucket):
+    """the GradientBucket whose decoder slice is all-reduced from inside backward (None: off); returns the previous one"""
+    prev = _OVERLAP_BUCKET[0]
+    _OVERLAP_BUCKET[0] = bucket
+    return prev
+
+
+class _BucketBoundary(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dec, bucket):
+        ctx.dec, ctx.bucket = dec, bucket
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not (dy.is_cuda and torch.cuda.is_current_stream_capturing()):      # a captured step exchanges after the replay
+            _flush_wgrad()                                   # decoder weight gradients: slab -> OIHW slices of the arena, now
+            ctx.bucket.begin_early([p for p in ctx.dec.parameters() if p.requires_grad])
+        return dy, None, None
+
+
 def decoder_forward(dec, fmaps, t):
     """Decoder.forward up to (not including) final_layer.conv: the 4 residual blocks and the final block's upsampling convolution"""
     cur = fmaps[4]
+    if _OVERLAP_BUCKET[0] is not None and torch.is_grad_enabled() and cur.requires_grad:
+        cur = _BucketBoundary.apply(cur, dec, _OVERLAP_BUCKET[0])
     blocks = list(dec.residual_layers)
     tbs = [None] * len(blocks)
     if t is not None and len(blocks) <= 8:                   # every block has its own embedding + projection (:606-609)

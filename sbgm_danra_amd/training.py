@@ -165,10 +165,20 @@ class TrainingPipeline_general:
         if use_mixed_precision:
             raise NotImplementedError("fp32 only: the reference's autocast branch is commented out (training.py:325-343)")
         self.model.train()
-        if self._bucket is None and parallel.world()[1] > 1:
+        world = parallel.world()[1]
+        if self._bucket is None and world > 1:
             self._bucket = parallel.GradientBucket(self.model)
+        # 1 / world rides on the optimizer launch when the optimizer can take it (optim.Adam / AdamW), else the bucket divides
+        fold = self._bucket is not None and hasattr(self.optimizer, "grad_scale")
+        if fold:
+            self.optimizer.grad_scale = 1.0 / world
         loss_sum = 0.0
         use_graph = bool(self.cfg["training"].get("use_hip_graph", False)) and torch.device(self.device).type == "cuda"
+        from . import train_graph
+        if use_graph and train_graph._sync_world() is not None:
+            raise ValueError("training.sync_batchnorm needs host-driven collectives between kernel halves and cannot run inside a captured "
+                             "step: set training.use_hip_graph: false (or sync_batchnorm: false)")
+        prev_overlap = train_graph.set_overlap_bucket(self._bucket if not use_graph else None)
         for idx, samples in enumerate(dataloader):
             if use_graph:
                 x, batch_loss = self._graph_step(samples)
@@ -179,9 +189,10 @@ class TrainingPipeline_general:
             if self.extreme_enabled and idx % self.extreme_every_step == 0:
                 self._check_ground_truth(x)
             if self._bucket is not None:
-                self._bucket.all_reduce_()            # the one collective of the path
+                self._bucket.all_reduce_(average=not fold)   # the exchange step of the path (its decoder part started inside backward)
             self.optimizer.step()
             loss_sum += batch_loss.item()
+        train_graph.set_overlap_bucket(prev_overlap)
         avg = loss_sum / max(1, len(dataloader))
         if verbose:
             logger.info(f"→ Epoch {current_epoch}/{epochs} completed: Avg. training Loss: {avg:.4f}")

@@ -303,7 +303,7 @@ def _bucket_views_case(rank, world, out_dir):
         (net(x) ** 2).mean().backward()
         local = [p.grad.clone() for p in net.parameters() if p.requires_grad]
         bucket.all_reduce_()
-        flat, views = bucket._layout()
+        flat, views, _offs = bucket._layout()
         assert all(p.grad.data_ptr() == v.data_ptr() for p, v in zip(bucket.params, views))
         torch.save(local, os.path.join(out_dir, f"local{rank}_{step}.pt"))
         torch.save([p.grad.clone() for p in bucket.params], os.path.join(out_dir, f"avg{rank}_{step}.pt"))
@@ -315,6 +315,57 @@ def test_gradient_bucket_on_a_model_repoints_grads_into_the_flat_tensor(tmp_path
         l0, l1, a0, a1 = (torch.load(tmp_path / f"{n}_{step}.pt", weights_only=True) for n in ("local0", "local1", "avg0", "avg1"))
         for x0, x1, y0, y1 in zip(l0, l1, a0, a1):
             assert torch.equal(y0, y1) and torch.allclose(y0, (x0 + x1) / 2, rtol=1e-6, atol=1e-8)
+
+
+def _bucket_overlap_case(rank, world, out_dir):
+    """two-part network ("encoder" | "decoder"): the decoder slice is all-reduced asynchronously from INSIDE backward (a hook on
+    the boundary activation, as train_graph._BucketBoundary does on the bottleneck feature map), the rest afterwards.  Must equal the
+    single all-reduce bit for bit; with average=False the flat tensor holds the SUM (the optimizer launch applies 1 / world)."""
+    torch.manual_seed(0)
+    enc = nn.Sequential(nn.Conv2d(2, 4, 3, padding=1), nn.GroupNorm(2, 4))
+    dec = nn.Sequential(nn.Conv2d(4, 4, 3, padding=1), nn.Conv2d(4, 1, 1))
+    net = nn.Sequential(enc, dec)
+    extra = nn.Parameter(torch.zeros(3))                         # trainable, never used: no local gradient on any rank
+    dec.register_parameter("unused", extra)
+    parallel.broadcast_parameters(net)
+    x = torch.randn(4, 2, 6, 6, generator=torch.Generator().manual_seed(10 + rank))
+    results = {}
+    for mode in ("single", "overlap", "sum"):
+        bucket = parallel.GradientBucket(net)
+        net.zero_grad(set_to_none=True)
+        h = enc(x)
+        if mode != "single":
+            h.register_hook(lambda g, b=bucket: (b.begin_early(list(dec.parameters())), g)[1])
+        (dec(h) ** 2).mean().backward()
+        assert extra.grad is None
+        bucket.all_reduce_(average=mode != "sum")
+        assert bucket.early == (0 if mode == "single" else 1)
+        assert extra.grad is not None and float(extra.grad.abs().sum()) == 0.0     # every rank steps it alike (ADVICE r2)
+        flat = bucket._layout()[0]
+        results[mode] = flat.clone()
+    assert torch.equal(results["single"], results["overlap"])
+    assert torch.equal(results["sum"] / world, results["single"])
+    torch.save(results["single"], os.path.join(out_dir, f"flat{rank}.pt"))
+
+
+def test_overlapped_bucket_equals_single_all_reduce(tmp_path):
+    _spawn(_bucket_overlap_case, tmp_path)
+    assert torch.equal(torch.load(tmp_path / "flat0.pt", weights_only=True), torch.load(tmp_path / "flat1.pt", weights_only=True))
+
+
+def test_sync_batchnorm_refuses_captured_steps(monkeypatch):
+    """SyncBatchNorm needs host-driven collectives between kernel halves: the pipeline must refuse use_hip_graph with it before any
+    warm-up / capture, not fail inside torch.cuda.graph"""
+    from sbgm_danra_amd import train_graph, training
+    pipe = training.TrainingPipeline_general.__new__(training.TrainingPipeline_general)
+    pipe.cfg = {"training": {"use_hip_graph": True}}
+    pipe.device = "cuda"
+    pipe.model = nn.Linear(2, 2)
+    pipe._bucket = None
+    pipe.optimizer = torch.optim.SGD(pipe.model.parameters(), lr=0.1)
+    monkeypatch.setattr(train_graph, "_sync_world", lambda: object())
+    with pytest.raises(ValueError, match="sync_batchnorm"):
+        pipe.train_batches([], epochs=1, verbose=False)
 
 
 # ---- full-domain tiles over ranks (stub sampler) ---------------------------------------------------------------------------

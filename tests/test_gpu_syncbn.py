@@ -142,3 +142,46 @@ def test_two_rank_step_with_syncbn_equals_the_full_batch_step(tmp_path):
     assert maxrel(got["bn1_rv"], want_rv) < 1e-5
     plain = torch.load(tmp_path / "sync0.pt", weights_only=True)
     assert max(maxrel(plain["grads"][k], want[k]) for k in want) > 1e-2      # per-replica statistics are a different step
+
+
+def _overlap_main(rank, world, port, out_dir):
+    """the real network, two ranks on one card (gloo): backward with the decoder slice all-reduced from inside backward
+    (train_graph._BucketBoundary) against the single all-reduce after backward; sums must be bit-identical"""
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch.distributed as dist
+    import sbgm_danra_amd as S
+    from sbgm_danra_amd import parallel, train_graph
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        torch.cuda.set_device(0)
+        _, net, _ = build_pair(1)
+        net.train()
+        x, cond, t, z = _batch()
+        sl = slice(rank * 2, rank * 2 + 2)
+        flats, early = {}, {}
+        for mode in ("single", "overlap"):
+            bucket = parallel.GradientBucket(net)
+            train_graph.set_overlap_bucket(bucket if mode == "overlap" else None)
+            net.zero_grad(set_to_none=True)
+            loss = S.loss_fn(net, x[sl].cuda(), S.marginal_prob_std_fn, cond_img=cond[sl].cuda(), noise=(t[sl].cuda(), z[sl].cuda()))
+            loss.backward()
+            bucket.all_reduce_(average=False)
+            torch.cuda.synchronize()
+            flats[mode], early[mode] = bucket._layout()[0].clone().cpu(), bucket.early
+            assert bucket.copies == 0
+        train_graph.set_overlap_bucket(None)
+        assert early == {"single": 0, "overlap": 1}
+        # atomically accumulated gradients differ between two backward passes by summation order; everything else is bit-equal
+        same = float((flats["single"] == flats["overlap"]).float().mean())
+        err = maxrel(flats["overlap"], flats["single"])
+        if rank == 0:
+            torch.save({"same": same, "err": err}, os.path.join(out_dir, "overlap.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_overlapped_gradient_exchange_equals_single_all_reduce(tmp_path):
+    mp.spawn(_overlap_main, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    got = torch.load(tmp_path / "overlap.pt", weights_only=True)
+    print("overlapped vs single all-reduce: identical elements", got["same"], "max-rel", got["err"])
+    assert got["err"] < 1e-5 and got["same"] > 0.5
