@@ -236,6 +236,9 @@ int sbgm_set_scratch_prezeroed(int on);
 int sbgm_wgrad_defer(int on);
 int sbgm_wgrad_flush(void* stream);
 int sbgm_wgrad_flush_pending(void);
+/* Forget the queued conversions without running them (returns how many): after a backward pass that raised, the queued dw_oihw
+ * destinations may already be freed, and the next backward recomputes every gradient anyway. */
+int sbgm_wgrad_discard(void);
 /* Winograd F(2,3)-along-rows weight transform for 3x3 kernels: OIHW -> U[kh][c/16][xi][Cout][16] */
 int64_t sbgm_conv_wino_packed_numel(int Cout, int c_pad);
 int sbgm_conv_wino_pack_weight(const float* w_oihw, float* packed, int Cout, int Cin, int c_pad, void* stream);

@@ -123,6 +123,7 @@ SIGNATURES = {
     "sbgm_wgrad_defer": (_i, [_i]),
     "sbgm_wgrad_flush": (_i, [_vp]),
     "sbgm_wgrad_flush_pending": (_i, []),
+    "sbgm_wgrad_discard": (_i, []),
     "sbgm_attn_qkv_fwd": (_i, [_vp] * 6 + [_i, _i, _f, _vp]),
     "sbgm_attn_tail_fwd": (_i, [_vp] * 11 + [_i, _i, _f, _vp]),
     "sbgm_time_proj_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

@@ -1133,6 +1133,8 @@ static int unpack_or_queue(const float* src, float* dst, int Cout, int Cin, int 
 }
 
 int sbgm_wgrad_pending() { return (int)g_unpack_queue.size(); }
+// forget the queued layout passes without running them (a backward pass that raised: their destination tensors may be gone)
+void sbgm_wgrad_discard_queue() { g_unpack_queue.clear(); }
 
 int sbgm_launch_wgrad_flush(hipStream_t st) {
     size_t i = 0;

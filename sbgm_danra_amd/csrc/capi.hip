@@ -145,6 +145,7 @@ int sbgm_wgrad_defer(int on) {
 }
 int sbgm_wgrad_flush(void* stream) { return sbgm_launch_wgrad_flush(ST); }
 int sbgm_wgrad_flush_pending(void) { return sbgm_wgrad_pending(); }
+int sbgm_wgrad_discard(void) { const int n = sbgm_wgrad_pending(); sbgm_wgrad_discard_queue(); return n; }
 
 int sbgm_conv2d_tune(const sbgm_conv_args* a, int* tile, void* stream) {
     SBGM_CHECK(a && tile && a->x && a->w_packed && a->out, "conv2d_tune: null argument");

@@ -66,6 +66,7 @@ int sbgm_launch_conv(const ConvGeom& g, ConvParams p, const ConvTile& cfg, float
 extern int sbgm_scratch_prezeroed;
 extern int sbgm_wgrad_deferred;                 // backward.hip: queue the slab -> OIHW passes for sbgm_launch_wgrad_flush
 int sbgm_wgrad_pending();
+void sbgm_wgrad_discard_queue();
 int sbgm_launch_wgrad_flush(hipStream_t st);
 
 // ---- conv_wino.hip: 3x3 stride-1 pad-1 convolution, 1-D Winograd F(2,3) along rows ------------------------------------

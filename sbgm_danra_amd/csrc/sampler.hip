@@ -111,7 +111,8 @@ __global__ __launch_bounds__(256) void langevin_kernel(float* __restrict__ x, co
     if (state) seed = state->seed;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         if (per_tile) {
-            const float rt = snr_noise_norm / (float)sqrt(sumsq[i / per4]);
+            // a tile whose score is exactly zero (masked / constant tile) would get eps = inf and poison the stitched domain
+            const float rt = snr_noise_norm / fmaxf((float)sqrt(sumsq[i / per4]), 1e-12f);
             eps = 2.f * (rt * rt);
             nz = sqrtf(2.f * eps);
         }

@@ -265,6 +265,8 @@ class _Engine:
             mods = self._mods = list(net.modules())
         out = [N.generation()]
         for m in mods:
+            for c in m._modules.values():                # a replaced sub-module (net.decoder = ..., a swapped attention block)
+                out.append(id(c))                        # changes the key, so the full check below rebuilds the list
             for v in m._parameters.values():
                 if v is not None:
                     out.append((id(v), v.data_ptr(), v._version))

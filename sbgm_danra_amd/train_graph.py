@@ -56,8 +56,8 @@ _ZERO = {}             # device -> [buffer, offset, high-water mark, usable exte
 
 
 def _zero_reset(dev):
-    if _L().sbgm_wgrad_flush_pending():           # a backward pass that raised before its end-of-pass callback: finish it
-        N.check(_L().sbgm_wgrad_flush(_st()))
+    if _L().sbgm_wgrad_flush_pending():           # a backward pass that raised before its end-of-pass callback: its queued layout
+        _L().sbgm_wgrad_discard()                 # passes point at gradient tensors that may be freed by now — drop them unrun
     _FLUSH_QUEUED[0] = False
     z = _ZERO.get(dev)
     if z is None:

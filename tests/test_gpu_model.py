@@ -379,3 +379,22 @@ def test_cached_step_graph_is_reused_across_runs_with_other_seeds_and_lengths():
         assert torch.equal(c, a)
         d = sampler(net, S.marginal_prob_std_fn, S.diffusion_coeff_fn, num_steps=7, seed=2, use_graph=True, **kw)
         assert not torch.equal(d, a)
+
+
+def test_replaced_submodule_is_seen_by_the_engine():
+    """The engine keeps a repacked copy of the weights and checks a cached module list for changes on every call (0.1 ms).  A
+    sub-module replaced AFTER the first forward (same parameter shapes, other values) must be picked up: the key includes the
+    identity of every module's children."""
+    import copy
+    _, net, _ = build_pair(1)
+    net.eval()
+    g = torch.Generator().manual_seed(5)
+    x, c, t = torch.randn(1, 1, 64, 64, generator=g).cuda(), torch.randn(1, 1, 64, 64, generator=g).cuda(), torch.tensor([0.4]).cuda()
+    with torch.no_grad():
+        y0 = net(x, t, cond_img=c).clone()
+        new_block = copy.deepcopy(net.decoder.residual_layers[3])
+        for p in new_block.parameters():
+            p.mul_(1.5)
+        net.decoder.residual_layers[3] = new_block           # a different module object with different weights
+        y1 = net(x, t, cond_img=c)
+    assert maxrel(y1.cpu(), y0.cpu()) > 1e-3
