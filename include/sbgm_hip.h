@@ -388,6 +388,8 @@ int sbgm_act_bwd(const float* x, const float* dy, float* dx, int64_t n, int act,
  * loss_fwd: loss[0] = mean_b sum_{chw} w*(score*std_b + z)^2, w = sigmoid(sdf)*0.5+0.5 or 1 (sdf NULL)           (:974-984);
  *   partial_ws: >= 8 * B * sbgm_dsm_loss_blocks(per_sample) bytes (one fp64 partial per workgroup, summed in fixed order).
  * loss_bwd: dscore = dloss[0] * (2/B) * w * (score*std_b + z) * std_b   (dloss: DEVICE scalar, autograd's grad_output). */
+/* perturb with another schedule (loss_fn takes any marginal_prob_std callable, :936-985): call once with per_sample = 0 (only t_out is
+ * drawn / copied), evaluate the schedule on t_out into std_out, call again with t = t_out and sigma <= 0: std_out is then READ. */
 int sbgm_dsm_loss_blocks(int64_t per_sample);
 int sbgm_dsm_perturb(const float* x, const float* z, const float* t, const uint64_t* rng_state, uint64_t seed, float t_eps, float sigma,
                      float* x_perturbed, float* z_out, float* t_out /* [B] */, float* std_out /* [B] */, int B,

@@ -29,10 +29,11 @@ __global__ __launch_bounds__(256) void dsm_perturb_kernel(const float* __restric
     float t;
     if (t_in) t = t_in[b];
     else t = philox_uniform4(seed, 2ull * off, (unsigned long long)b)[0] * (1.f - t_eps) + t_eps;          // :957
-    const float sd = ve_std(t, sigma);
+    // sigma > 0: the VE schedule; sigma <= 0: std_out[b] holds the caller's marginal_prob_std(t_b) on entry (any schedule)
+    const float sd = sigma > 0.f ? ve_std(t, sigma) : std_out[b];
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         t_out[b] = t;
-        std_out[b] = sd;
+        if (sigma > 0.f) std_out[b] = sd;
     }
     const size_t base = (size_t)b * per4;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < per4; i += (size_t)gridDim.x * blockDim.x) {
@@ -117,9 +118,9 @@ int sbgm_dsm_nblk(int64_t per_sample) { return dsm_blocks((size_t)per_sample / 4
 int sbgm_launch_dsm_perturb(const float* x, const float* z_in, const float* t_in, const unsigned long long* rng,
                             unsigned long long seed, float t_eps, float sigma, float* xp, float* z_out, float* t_out, float* std_out, int B, size_t per, hipStream_t st) {
     SBGM_CHECK(x && xp && t_out && std_out, "dsm_perturb: x, xp, t_out and std_out are required");
-    SBGM_CHECK(B >= 1 && per >= 4 && per % 4 == 0, "dsm_perturb: B=%d, per-sample size %zu must be a positive multiple of 4", B, per);
-    SBGM_CHECK(z_in || z_out, "dsm_perturb: z_out is required when the noise is drawn in the kernel");
-    hipLaunchKernelGGL(dsm_perturb_kernel, dim3(dsm_blocks(per / 4), B), dim3(256), 0, st, x, z_in, t_in, rng, seed, t_eps, sigma, xp, z_out,
+    SBGM_CHECK(B >= 1 && per % 4 == 0, "dsm_perturb: B=%d, per-sample size %zu must be a multiple of 4", B, per);
+    SBGM_CHECK(per == 0 || z_in || z_out, "dsm_perturb: z_out is required when the noise is drawn in the kernel");
+    hipLaunchKernelGGL(dsm_perturb_kernel, dim3(per ? dsm_blocks(per / 4) : 1, B), dim3(256), 0, st, x, z_in, t_in, rng, seed, t_eps, sigma, xp, z_out,
                        t_out, std_out, per / 4);
     SBGM_LAUNCH_CHECK();
     return 0;

@@ -85,6 +85,7 @@ class GradientBucket:
         self.early = 0                                  # asynchronous early all-reduces launched (diagnostic)
         self._pending = None                            # (work handle, first element, end element) of the early slice
         self._index = {id(p): i for i, p in enumerate(self.params)}
+        self._absent = {}                               # parameter index -> True when no rank ever produces its gradient
 
     def _layout(self):
         """(flat tensor, [view per parameter], [offset per parameter])"""
@@ -153,8 +154,16 @@ class GradientBucket:
             dist.all_reduce(flat[:end], op=dist.ReduceOp.SUM)
         if n_rest < len(self.params):
             work.wait()
-        for i in missing:                               # no local gradient: every rank must still step this parameter alike
-            self.params[i].grad = views[i]
+        # No local gradient.  If another rank produced one, this rank must step the parameter with the same averaged gradient or
+        # the replicas diverge; if no rank did (the final block's unused time projection), it must stay without a gradient, as in
+        # the single-device reference (a zero gradient would still apply weight decay).  Which of the two holds is decided once
+        # per parameter, on the first step it is seen missing (one device->host check), and remembered.
+        for i in missing:
+            known = self._absent.get(i)
+            if known is None:
+                known = self._absent[i] = not bool(views[i].any())
+            if not known:
+                self.params[i].grad = views[i]
         if average:
             flat.div_(ws)
 

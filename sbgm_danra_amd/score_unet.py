@@ -364,9 +364,7 @@ class ScoreNet(nn.Module):
         x, t, y, cond_img, lsm_cond, topo_cond = self._prep(x, t, y, cond_img, lsm_cond, topo_cond)
         if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
             # training: op-by-op graph of native kernels with hand-written backward passes (train_graph.py)
-            if not self.training:
-                raise NotImplementedError("gradients through an eval()-mode (running-statistics BatchNorm) network are not "
-                                          "implemented; call model.train() or evaluate under torch.no_grad()")
+            # (eval mode too: BatchNorm then uses its running statistics and stays differentiable, as in the reference)
             if _fmaps is not None:
                 raise ValueError("_fmaps is an inference-only debugging hook")
             from .train_graph import forward_train
@@ -490,15 +488,16 @@ def loss_fn(model, x, marginal_prob_std, t_eps=1e-3, device=None, y=None, cond_i
     Noise: drawn inside the perturbation kernel (Philox) from a seed taken from torch's CPU generator per call, so
     `torch.manual_seed` makes a run repeatable; while a hipGraph is being captured the seed / offset pair lives on the device
     and the loss kernel advances it, so every replay perturbs with fresh noise.  Keyword-only `noise=(t, z)` (not in the
-    reference) injects the draws for parity runs.  `marginal_prob_std` must be the VE schedule of this module (any sigma)."""
+    reference) injects the draws for parity runs.  `marginal_prob_std`: this module's VE schedule (evaluated inside the kernel) or
+    any callable [B] -> [B] (evaluated on the drawn t with torch, between two launches of the perturbation kernel)."""
     N.require_device(x)
     for name, arr in (("cond_img", cond_img), ("lsm_cond", lsm_cond), ("topo_cond", topo_cond), ("y", y)):
         if arr is not None and arr.shape[0] != x.shape[0]:
             raise ValueError(f"Batch size mismatch: x={x.shape[0]}, {name}={arr.shape[0]}")
-    if getattr(marginal_prob_std, "func", marginal_prob_std) is not globals()["marginal_prob_std"]:
-        raise NotImplementedError("the native loss implements the VE-SDE marginal_prob_std of this module (reference "
-                                  "score_unet.py:881-897); pass functools.partial(marginal_prob_std, sigma=...)")
-    sigma = _sigma_of(marginal_prob_std)
+    # the module's own VE schedule is evaluated inside the perturbation kernel; any other callable (the reference accepts an
+    # arbitrary marginal_prob_std, :936) is evaluated on the drawn t between two launches of the same kernel
+    own_ve = getattr(marginal_prob_std, "func", marginal_prob_std) is globals()["marginal_prob_std"]
+    sigma = _sigma_of(marginal_prob_std) if own_ve else 0.0
     xc = N.f32c(x)
     B, per = xc.shape[0], xc[0].numel()
     dev = xc.device
@@ -521,6 +520,12 @@ def loss_fn(model, x, marginal_prob_std, t_eps=1e-3, device=None, y=None, cond_i
     random_t, std = torch.empty(B, device=dev), torch.empty(B, device=dev)
     perturbed_x = torch.empty_like(xc)
     z = z_in if z_in is not None else torch.empty_like(xc)
+    if not own_ve:
+        N.check(lib.sbgm_dsm_perturb(xc.data_ptr(), None, N.ptr(t_in), N.ptr(rng), seed, float(t_eps), 1.0,
+                                     perturbed_x.data_ptr(), None, random_t.data_ptr(), std.data_ptr(), B, 0, N.stream()))   # t only
+        user_std = marginal_prob_std(random_t)
+        std.copy_(torch.as_tensor(user_std, dtype=torch.float32, device=dev).reshape(-1).expand(B))
+        t_in = random_t
     N.check(lib.sbgm_dsm_perturb(xc.data_ptr(), N.ptr(z_in), N.ptr(t_in), N.ptr(rng), seed, float(t_eps), sigma,
                                  perturbed_x.data_ptr(), z.data_ptr(), random_t.data_ptr(), std.data_ptr(), B, per, N.stream()))
     score = model(perturbed_x, random_t, y=y, cond_img=cond_img, lsm_cond=lsm_cond, topo_cond=topo_cond)

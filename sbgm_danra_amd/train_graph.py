@@ -846,22 +846,58 @@ def _bn(x, bn, res=None, tb_after=None, relu=True):
     return y
 
 
+class BNEvalFn(torch.autograd.Function):
+    """y = relu?(BatchNorm_eval(x) [+ res]) [+ tbias_after] with the RUNNING statistics (module.eval()), differentiable: the
+    reference's ScoreNet.forward builds an autograd graph in any mode (score_unet.py:829-879).  Forward = the apply half of the
+    train-mode kernel fed sums that reproduce (running_mean, running_var) exactly; the running statistics stay untouched.
+    Backward = the SyncBatchNorm backward halves with zero batch-mean terms: dx = gamma * rstd * g (no dependence of the statistics
+    on x), dgamma = sum g * xhat, dbeta = sum g."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, rm, rv, res, tb_after, relu, eps):
+        B, H, W, Cc = x.shape
+        n = float(B * H * W)
+        rmd, rvd = rm.double(), rv.double()
+        ws = torch.empty(3 * Cc, dtype=torch.float64, device=x.device)              # (sum x, sum x^2) pairs + room for (mean, rstd)
+        ws[:2 * Cc] = torch.stack([rmd * n, (rvd + rmd * rmd) * n], 1).reshape(-1)
+        y = torch.empty_like(x)
+        mr = torch.empty(Cc, 2, device=x.device)
+        N.check(_L().sbgm_batchnorm_train_apply(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), None, None, N.ptr(res),
+                                                N.ptr(tb_after), int(relu), B, H * W, Cc, eps, 0.0, ws.data_ptr(), n, mr.data_ptr(), _st()))
+        ctx.save_for_backward(x, y, gamma, beta, tb_after, mr)
+        ctx.cfg = (relu, res is not None, tb_after is not None)
+        ctx.arena = _ACTIVE_ARENA[0]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y, gamma, beta, tb_after, mr = ctx.saved_tensors
+        relu, has_res, has_tb = ctx.cfg
+        dy = dy.contiguous()
+        B, H, W, Cc = x.shape
+        dx, dres = torch.empty_like(x), (torch.empty_like(x) if has_res else None)
+        dg, _ = _pgrad(ctx.arena, gamma, False)
+        db, _ = _pgrad(ctx.arena, beta, False)
+        s12, pooled = _zeros(B * Cc * 2, x.device)
+        with _prezeroed(pooled):
+            N.check(_L().sbgm_batchnorm_bwd_reduce(x.data_ptr(), dy.data_ptr(), y.data_ptr(), N.ptr(tb_after), mr.data_ptr(), int(relu),
+                                                   s12.data_ptr(), B, H * W, Cc, _st()))
+        zero = torch.zeros(2 * Cc, device=x.device)                                   # batch-mean terms: none in eval mode
+        N.check(_L().sbgm_batchnorm_bwd_apply(x.data_ptr(), dy.data_ptr(), y.data_ptr(), gamma.data_ptr(), N.ptr(tb_after), mr.data_ptr(),
+                                              int(relu), dx.data_ptr(), N.ptr(dres), dg.data_ptr(), db.data_ptr(), s12.data_ptr(),
+                                              zero.data_ptr(), float(B * H * W), B, H * W, Cc, _st()))
+        dtb = None
+        if has_tb:
+            dtb, zeroed = _grad_zeros(B * Cc, x.device)
+            dtb = dtb.view(B, Cc)
+            with _prezeroed(zeroed):
+                N.check(_L().sbgm_samplesum(dy.data_ptr(), dtb.data_ptr(), B, H * W, Cc, _st()))
+        return dx, dg, db, None, None, dres, dtb, None, None
+
+
 def _bn_eval(x, bn, res, tb_after, relu):
-    """BatchNorm2d with running statistics (module.eval()), for stand-alone sub-module calls under no_grad: the apply half of the
-    train-mode kernel, fed sums that reproduce (running_mean, running_var) exactly, running statistics left untouched."""
-    if torch.is_grad_enabled() and (x.requires_grad or bn.weight.requires_grad):
-        raise NotImplementedError("gradients through an eval()-mode (running-statistics BatchNorm) network are not implemented; "
-                                  "call .train() or evaluate under torch.no_grad()")
-    B, H, W, Cc = x.shape
-    n = float(B * H * W)
-    rm, rv = bn.running_mean.double(), bn.running_var.double()
-    sums = torch.stack([rm * n, (rv + rm * rm) * n], 1).contiguous()            # [C][2] fp64: (sum x, sum x^2)
-    ws = torch.empty(3 * Cc, dtype=torch.float64, device=x.device)              # sums + the (mean, rstd) pairs behind them
-    ws[:2 * Cc] = sums.view(-1)
-    y = torch.empty_like(x)
-    N.check(_L().sbgm_batchnorm_train_apply(x.data_ptr(), y.data_ptr(), bn.weight.data_ptr(), bn.bias.data_ptr(), None, None, N.ptr(res),
-                                            N.ptr(tb_after), int(relu), B, H * W, Cc, bn.eps, 0.0, ws.data_ptr(), n, None, _st()))
-    return y
+    """BatchNorm2d with running statistics (module.eval())"""
+    return BNEvalFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, res, tb_after, relu, bn.eps)
 
 
 def _attention(mod, x):                               # x: [B, H, W, C] -> same (reference score_unet.py:136-148)

@@ -340,11 +340,21 @@ def _bucket_overlap_case(rank, world, out_dir):
         assert extra.grad is None
         bucket.all_reduce_(average=mode != "sum")
         assert bucket.early == (0 if mode == "single" else 1)
-        assert extra.grad is not None and float(extra.grad.abs().sum()) == 0.0     # every rank steps it alike
+        assert extra.grad is None                                    # unused on every rank: stays without a gradient (no weight decay)
         flat = bucket._layout()[0]
         results[mode] = flat.clone()
     assert torch.equal(results["single"], results["overlap"])
     assert torch.equal(results["sum"] / world, results["single"])
+    # a parameter only rank 0 uses: rank 1 must receive the averaged gradient (replicas would diverge otherwise)
+    lone = nn.Parameter(torch.ones(5))
+    dec.register_parameter("lone", lone)
+    bucket = parallel.GradientBucket(net)
+    net.zero_grad(set_to_none=True)
+    out = (dec(enc(x)) ** 2).mean() + (lone.sum() * 3.0 if rank == 0 else 0.0)
+    out.backward()
+    assert (lone.grad is None) == (rank != 0)
+    bucket.all_reduce_()
+    assert lone.grad is not None and torch.allclose(lone.grad, torch.full((5,), 3.0 / world))
     torch.save(results["single"], os.path.join(out_dir, f"flat{rank}.pt"))
 
 

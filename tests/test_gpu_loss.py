@@ -82,8 +82,6 @@ def test_loss_fn_argument_checks():
     x = torch.randn(2, 1, 32, 32).cuda()
     with pytest.raises(ValueError):
         S.loss_fn(net, x, S.marginal_prob_std_fn, cond_img=torch.randn(3, 1, 32, 32).cuda())        # reference :965-967
-    with pytest.raises(NotImplementedError):
-        S.loss_fn(net, x, lambda t: t, cond_img=torch.randn(2, 1, 32, 32).cuda())
     with pytest.raises(N.NativeError):
         S.loss_fn(net, x.cpu(), S.marginal_prob_std_fn, cond_img=torch.randn(2, 1, 32, 32))
     # another sigma is honoured (perturbation and loss use the schedule's own sigma)
@@ -96,6 +94,65 @@ def test_loss_fn_argument_checks():
         return torch.zeros_like(xp)
     S.loss_fn(model, x, fn10, noise=(t, z))
     assert maxrel(seen["xp"].cpu(), (x + fn10(t)[:, None, None, None] * z).cpu()) < 1e-6
+
+
+def test_loss_fn_takes_any_marginal_prob_std_callable():
+    """reference loss_fn accepts an arbitrary marginal_prob_std (score_unet.py:936-985): a VP-like schedule here.  Perturbation, loss
+    value and d loss / d score against the reference expressions in PyTorch, with injected (t, z) and with in-kernel draws (the
+    t that was drawn is the t the callable saw)."""
+    import sbgm_danra_amd as S
+    sched = lambda t: torch.sqrt(1.0 - torch.exp(-0.1 * t - 9.95 * t * t))          # noqa: E731
+    g = torch.Generator().manual_seed(3)
+    x, z = torch.randn(3, 1, 32, 32, generator=g).cuda(), torch.randn(3, 1, 32, 32, generator=g).cuda()
+    t = (torch.rand(3, generator=g) * 0.9 + 0.05).cuda()
+    seen = {}
+
+    def model(xp, tt, **kw):
+        seen["xp"], seen["t"] = xp, tt
+        s = (xp * 0.3).requires_grad_(True)
+        seen["s"] = s
+        return s
+    loss = S.loss_fn(model, x, sched, noise=(t, z))
+    loss.backward()
+    std = sched(t)[:, None, None, None]
+    assert torch.equal(seen["t"], t) and maxrel(seen["xp"].cpu(), (x + std * z).cpu()) < 1e-6
+    sr = (seen["xp"].detach() * 0.3).requires_grad_(True)
+    want = torch.mean(torch.sum((sr * std + z) ** 2, dim=(1, 2, 3)))
+    want.backward()
+    assert abs(float(loss) / float(want) - 1) < 1e-6 and maxrel(seen["s"].grad.cpu(), sr.grad.cpu()) < 1e-6
+    torch.manual_seed(11)
+    S.loss_fn(model, x, sched)                                                       # draws inside the kernel
+    t2, xp2 = seen["t"].clone(), seen["xp"].clone()
+    assert float(t2.min()) >= 1e-3 and float(t2.max()) <= 1.0
+    zz = (xp2 - x) / sched(t2)[:, None, None, None]
+    assert abs(float(zz.mean())) < 0.1 and abs(float(zz.std()) - 1) < 0.1
+    torch.manual_seed(11)
+    S.loss_fn(model, x, sched)
+    assert torch.equal(seen["t"], t2) and torch.equal(seen["xp"], xp2)               # repeatable under torch.manual_seed
+
+
+def test_gradients_through_an_eval_mode_network(golden_dir):
+    """reference ScoreNet.forward is differentiable in any mode (score_unet.py:829-879): in eval() BatchNorm uses its running statistics
+    (dx = gamma * rstd * g).  Loss and every parameter gradient against autograd through the CPU oracle in eval mode."""
+    import sbgm_danra_amd as S
+    from oracle import torch_ref as O
+    ora, net, _ = build_pair(1)
+    ora.eval()
+    net.eval()
+    g = torch.Generator().manual_seed(9)
+    x, c = torch.randn(2, 1, 64, 64, generator=g), torch.randn(2, 1, 64, 64, generator=g)
+    t, z = torch.rand(2, generator=g) * 0.8 + 0.1, torch.randn(2, 1, 64, 64, generator=g)
+    want = O.loss_fn(ora, x, O.marginal_prob_std_fn, cond_img=c, noise=(t, z))
+    want.backward()
+    loss = S.loss_fn(net, x.cuda(), S.marginal_prob_std_fn, cond_img=c.cuda(), noise=(t.cuda(), z.cuda()))
+    loss.backward()
+    assert abs(float(loss) / float(want) - 1) < 1e-5
+    ref = dict(ora.named_parameters())
+    errs = {k: maxrel(p.grad.cpu(), ref[k].grad) for k, p in net.named_parameters() if ref[k].grad is not None}
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:3]
+    print("eval-mode gradients, worst max-rel:", worst)
+    assert len(errs) >= 160 and worst[0][1] < 1e-4, worst
+    assert int(net.encoder.bn1.num_batches_tracked) == int(ora.encoder.bn1.num_batches_tracked)       # running statistics untouched
 
 
 def test_in_kernel_noise_is_seeded_in_range_and_normal():
