@@ -141,6 +141,12 @@ def _pgrad(arena, like, zeroed):
     return torch.empty_like(like), False
 
 
+# Test instrumentation: when a list, every BatchNorm(+ReLU) forward appends the ReLU decision its backward will use
+# (relu output > 0, [B, H, W, C] bool).  tests/test_gpu_configs.py evaluates the float64 oracle under the SAME decisions: a
+# pre-activation within rounding distance of zero otherwise routes its gradient differently in two arithmetics, and one such flip
+# moves an encoder weight gradient by ~1e-2.
+_RELU_TRACE = [None]
+
 # SyncBatchNorm: statistics summed over the ranks of the process group, see BNTrainFn
 _SYNC_BN = [False]
 _SYNC_COUNT = [None]            # total batch size over the ranks for the current forward (device-independent python int)
@@ -524,6 +530,8 @@ class BNTrainFn(torch.autograd.Function):
                 N.check(_L().sbgm_batchnorm_train_apply(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(),
                                                         rv.data_ptr(), N.ptr(res), N.ptr(tb_after), int(relu), B, H * W, Cc, eps, momentum,
                                                         sums.data_ptr(), n_total, mr.data_ptr(), _st()))
+        if relu and _RELU_TRACE[0] is not None:
+            _RELU_TRACE[0].append(((y - tb_after.view(B, 1, 1, Cc)) if tb_after is not None else y) > 0)
         ctx.save_for_backward(x, y, gamma, beta, tb_after, mr)
         ctx.cfg = (relu, res is not None, tb_after is not None, n_total)
         ctx.arena = _ACTIVE_ARENA[0]
@@ -864,6 +872,8 @@ class BNEvalFn(torch.autograd.Function):
         mr = torch.empty(Cc, 2, device=x.device)
         N.check(_L().sbgm_batchnorm_train_apply(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), None, None, N.ptr(res),
                                                 N.ptr(tb_after), int(relu), B, H * W, Cc, eps, 0.0, ws.data_ptr(), n, mr.data_ptr(), _st()))
+        if relu and _RELU_TRACE[0] is not None:
+            _RELU_TRACE[0].append(((y - tb_after.view(B, 1, 1, Cc)) if tb_after is not None else y) > 0)
         ctx.save_for_backward(x, y, gamma, beta, tb_after, mr)
         ctx.cfg = (relu, res is not None, tb_after is not None)
         ctx.arena = _ACTIVE_ARENA[0]

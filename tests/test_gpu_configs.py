@@ -3,9 +3,9 @@ test_gpu_backward.py):
 
   C1  64x64, B=1, C_in=1 (no conditions), Euler-Maruyama: 5 injected-noise steps vs the oracle, then 50 steps
       (determinism, hipGraph replay == eager launches bit for bit)                      reference score_sampling.py:63-127
-  C3  128x128, 4 LR conditions (C_in=5), B=8: one training step — loss and EVERY parameter gradient vs CPU autograd of the
-      oracle (float64 evaluation as truth, fp32 evaluation beside it) with injected (t, z); the worst max-rel per parameter
-      group is printed                                                                 reference training.py:323-410
+  C3  128x128, 4 LR conditions (C_in=5), B=8: one training step — loss and EVERY parameter gradient vs a float64 evaluation of
+      the oracle under shared ReLU decisions (see the test), injected (t, z), synthetic weights and the reference's training
+      initialisation                                                                   reference training.py:188-201, :323-410
   C5  589x789 domain, 256x256 tiles, halo 32, predictor-corrector: end to end (shape, finite, deterministic, independent of
       how the tiles are batched) + one tile-sized network evaluation vs the oracle     (tiler: no reference counterpart)
 
@@ -69,56 +69,109 @@ def _group(name):
     return ".".join(name.split(".")[:2])
 
 
-def test_config3_training_step_128x128_batch8_all_gradients():
-    """Truth = the oracle evaluated in float64 (same algorithm, same fp32 weights / inputs / (t, z)).  Train-mode BatchNorm makes
-    some encoder gradients ill-conditioned at this shape: the reference's own fp32 CPU arithmetic is up to ~1e-2 away from the
-    float64 result there (printed), so fp32-vs-fp32 cannot separate rounding noise from an implementation error, float64 can.
-    It is the summation ORDER that moves them: the same fp32 CPU oracle changes by ~1e-2 on those tensors between 8 and 32
-    threads.  Asserted, per parameter: native vs float64 <= 1e-4 wherever the reference's own fp32 evaluation is that accurate on
-    the parameter's layer (the decoder and the deepest attention block: about half of the tensors), and everywhere
-    native error <= 1e-4 + 3 x the worst fp32-oracle error of the same layer (no worse than the reference's rounding noise)."""
+class _SharedReLU(torch.nn.Module):
+    """ReLU whose decisions come from a recorded list (in call order) instead of the sign of its own input"""
+
+    def __init__(self, masks, log):
+        super().__init__()
+        self.masks, self.log = masks, log
+
+    def forward(self, x):
+        m = next(self.masks)
+        self.log.append(int(((x > 0) != m).sum()))
+        return x * m.to(x.dtype)
+
+
+def _training_init(n_cond):
+    """the reference's training initialisation: torch's default module init under seed 42, then xavier_uniform on every Conv2d with
+    bias 0.01 (reference training.py:188-201, config default seed 42)"""
+    from oracle import torch_ref as O
+    torch.manual_seed(42)
+    ora = O.build_scorenet(n_cond)
+
+    def xavier(m):
+        if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d)):
+            torch.nn.init.xavier_uniform_(m.weight)
+            if m.bias is not None:
+                m.bias.data.fill_(0.01)
+    ora.apply(xavier)
+    return ora
+
+
+@pytest.mark.parametrize("init", ["synthetic", "training"])
+def test_config3_training_step_128x128_batch8_all_gradients(init):
+    """C3 per-GPU step (128x128, C_in = 5, B = 8, train-mode BatchNorm): loss and EVERY parameter gradient against a float64
+    evaluation of the oracle, for the hash-generated test weights and for the reference's training initialisation.
+
+    What the data says (tools/c3_grad_probe.py).  Compared naively, ~40-60 encoder gradients differ from float64 by
+    1e-3..3e-2 — for the native kernels AND for the reference's own fp32 CPU arithmetic alike, with either initialisation, with no
+    low-variance or dead BatchNorm channel anywhere (min batch variance 0.13).  The cause is discrete: the 17 ReLUs of the encoder
+    see ~2.6 M pre-activations, a handful of which lie within rounding distance of zero, and an arithmetic that lands on the other
+    side routes the gradient of that pixel differently; one flipped term of a weight-gradient sum of ~10^4 randomly signed terms is
+    a 1e-2 relative change.  So the comparison is made under SHARED ReLU decisions: the native forward records the decision its
+    backward uses (train_graph._RELU_TRACE) and the float64 oracle is evaluated with those decisions.  Then every one of the 163
+    gradients must hold 1e-4 — no tolerance here depends on the oracle's own error.  The naive comparison is printed, and asserted
+    where no ReLU lies between the parameter and the loss (the decoder)."""
     import copy
     import sbgm_danra_amd as S
     from oracle import torch_ref as O
+    from sbgm_danra_amd import train_graph
     torch.set_num_threads(max(1, min(32, os.cpu_count() or 1)))
-    ora, net, _ = build_pair(4)
+    if init == "synthetic":
+        ora, net, _ = build_pair(4)
+    else:
+        ora = _training_init(4)
+        _, net, _ = build_pair(4)
+        net.load_state_dict(ora.state_dict())
     ora.train(), net.train()
-    ora64 = copy.deepcopy(ora).double()
     g = torch.Generator().manual_seed(333)
     B = 8
     x, cond = torch.randn(B, 1, 128, 128, generator=g), torch.randn(B, 4, 128, 128, generator=g)
     t, z = torch.rand(B, generator=g) * 0.999 + 1e-3, torch.randn(B, 1, 128, 128, generator=g)
-    lo = O.loss_fn(ora, x, O.marginal_prob_std_fn, cond_img=cond, noise=(t, z))
-    lo.backward()
+    # native step, recording the ReLU decisions
+    train_graph._RELU_TRACE[0] = trace = []
+    try:
+        ln = S.loss_fn(net, x.cuda(), S.marginal_prob_std_fn, cond_img=cond.cuda(), noise=(t.cuda(), z.cuda()))
+    finally:
+        train_graph._RELU_TRACE[0] = None
+    ln.backward()
+    assert len(trace) == 17                                               # stem + 8 BasicBlocks x 2
+    masks = [m.permute(0, 3, 1, 2).cpu() for m in trace]                  # NHWC -> NCHW
+    # float64 oracle: free-running, and under the native decisions
+    ora64 = copy.deepcopy(ora).double()
     l64 = O.loss_fn(ora64, x.double(), O.marginal_prob_std_fn, cond_img=cond.double(), noise=(t, z.double()))
     l64.backward()
-    ln = S.loss_fn(net, x.cuda(), S.marginal_prob_std_fn, cond_img=cond.cuda(), noise=(t.cuda(), z.cuda()))
-    ln.backward()
-    loss_err = abs(float(ln.detach()) / float(l64.detach()) - 1)
-    po, p64, pn = dict(ora.named_parameters()), dict(ora64.named_parameters()), dict(net.named_parameters())
-    errs, ref_errs, groups, ref_groups = {}, {}, {}, {}
-    for k, p in p64.items():
+    shared = copy.deepcopy(ora).double()
+    flips = []
+    it = iter(masks)
+    for parent in [m for m in shared.encoder.modules() if isinstance(getattr(m, "relu", None), torch.nn.ReLU)]:
+        parent.relu = _SharedReLU(it, flips)
+    ls = O.loss_fn(shared, x.double(), O.marginal_prob_std_fn, cond_img=cond.double(), noise=(t, z.double()))
+    ls.backward()
+    assert len(flips) == 17 and next(it, None) is None
+    pn, p64, ps = dict(net.named_parameters()), dict(ora64.named_parameters()), dict(shared.named_parameters())
+    errs, naive = {}, {}
+    for k, p in ps.items():
         if p.grad is None:
             assert pn[k].grad is None, k
             continue
         errs[k] = maxrel(pn[k].grad.cpu().double(), p.grad)
-        ref_errs[k] = maxrel(po[k].grad.double(), p.grad)
-        groups[_group(k)] = max(groups.get(_group(k), 0.0), errs[k])
-        ref_groups[_group(k)] = max(ref_groups.get(_group(k), 0.0), ref_errs[k])
-    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:8]
-    worst_ref = sorted(ref_errs.items(), key=lambda kv: -kv[1])[:4]
-    print(f"C3 loss rel err vs float64 {loss_err:.2e}; worst native gradients vs float64: " + ", ".join(f"{k}={v:.2e}" for k, v in worst))
-    print("C3 fp32 CPU oracle vs float64 (the reference's own rounding noise): " + ", ".join(f"{k}={v:.2e}" for k, v in worst_ref))
-    print("C3 worst native max-rel per parameter group: " + ", ".join(f"{k}={v:.1e}" for k, v in sorted(groups.items())))
-    print("C3 worst fp32-oracle max-rel per parameter group: " + ", ".join(f"{k}={v:.1e}" for k, v in sorted(ref_groups.items())))
-    _record("c3", {"loss_rel_err": loss_err, "worst": worst, "worst_fp32_oracle": worst_ref, "groups": groups, "ref_groups": ref_groups,
-                   "n_params": len(errs), "all": errs, "all_fp32_oracle": ref_errs})
+        naive[k] = maxrel(pn[k].grad.cpu().double(), p64[k].grad)
+    loss_err = abs(float(ln.detach()) / float(ls.detach()) - 1)
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:6]
+    worst_naive = sorted(naive.items(), key=lambda kv: -kv[1])[:6]
+    n_elems = sum(m.numel() for m in masks)
+    print(f"C3[{init}] loss rel err {loss_err:.2e}; ReLU decisions that differ between the native fp32 forward and float64: {sum(flips)} of "
+          f"{n_elems} (per ReLU: {flips})")
+    print(f"C3[{init}] under shared decisions, worst of {len(errs)} gradients: " + ", ".join(f"{k}={v:.2e}" for k, v in worst))
+    print(f"C3[{init}] free-running float64 (for the record), worst: " + ", ".join(f"{k}={v:.2e}" for k, v in worst_naive)
+          + f"; {sum(1 for v in naive.values() if v > 1e-4)} tensors above 1e-4")
+    _record(f"c3_{init}", {"loss_rel_err": loss_err, "relu_flips": flips, "relu_elements": n_elems, "worst_shared": worst,
+                           "worst_free_running": worst_naive, "n_params": len(errs), "all_shared": errs, "all_free_running": naive})
     assert loss_err < 1e-5 and len(errs) >= 160
-    well = [k for k in errs if ref_groups[_group(k)] <= 1e-4]           # layers on which the reference's own fp32 arithmetic is accurate
-    assert len(well) >= 0.4 * len(errs), (len(well), len(errs))
-    assert max(errs[k] for k in well) <= 1e-4, sorted(((errs[k], k) for k in well), reverse=True)[:4]
-    over = {k: (errs[k], ref_groups[_group(k)]) for k in errs if errs[k] > 1e-4 + 3 * ref_groups[_group(k)]}
-    assert not over, over
+    assert worst[0][1] <= 1e-4, worst                                     # all 163, no slack
+    dec = [k for k in naive if k.startswith("decoder.")]                  # no ReLU between these and the loss: the naive comparison holds too
+    assert len(dec) >= 60 and max(naive[k] for k in dec) <= 1e-4, sorted(((naive[k], k) for k in dec), reverse=True)[:4]
     # the gradients of the step live in the model's flat arena (what the data-parallel all-reduce exchanges)
     from sbgm_danra_amd.train_graph import arena_for
     arena = arena_for(net, create=False)

@@ -8,7 +8,7 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
-from util_models import build_pair, load_golden, maxrel  # noqa: E402
+from util_models import build_pair, check_parity, load_golden, maxrel  # noqa: E402
 
 TOL = 1e-4
 CASES = {"fwd_b2_64_c2": (1, None), "fwd_b1_128_c7_y": (6, 4), "fwd_b2_32_c1": (0, None)}
@@ -32,7 +32,7 @@ def test_forward_matches_reference_goldens(golden_dir, name, mode):
     fm = []
     with torch.no_grad():
         out = net(g["x"].cuda(), g["t"].cuda(), _dev(g, "y"), _dev(g, "cond_img"), _dev(g, "lsm_cond"), _dev(g, "topo_cond"), _fmaps=fm)
-    assert maxrel(out.cpu(), g[f"score_{mode}"]) <= tol
+    check_parity(out.cpu(), g[f"score_{mode}"], tol, f"forward golden {name} {mode}")
     for i, f in enumerate(fm):          # encoder feature maps: strided NHWC subsample + abs-mean recorded from the reference
         flat = f.reshape(-1).cpu()
         sub = flat[:: max(1, flat.numel() // 4096)][:4096]
@@ -72,7 +72,7 @@ def test_forward_matches_oracle_fresh_inputs(B, hw, n_lr, geo, classes):
     with torch.no_grad():
         want = ora(x, t, y, cond, lsm, topo)
         got = net(cu(x), cu(t), cu(y), cu(cond), cu(lsm), cu(topo)).cpu()
-    assert maxrel(got, want) <= TOL
+    check_parity(got, want, TOL, f"forward fresh B{B} {hw}x{hw} c{n_cond}")
 
 
 def test_instance_norm_decoder_and_other_shapes():
@@ -90,7 +90,7 @@ def test_pc_sampler_matches_reference_golden(golden_dir):
     net.eval()
     got = S.pc_sampler(net, S.marginal_prob_std_fn, S.diffusion_coeff_fn, batch_size=2, num_steps=3, device="cuda", img_size=64,
                        cond_img=g["cond_img"].cuda(), noise=g["noise"])
-    assert maxrel(got.cpu(), g["x_mean"]) <= 1e-3
+    check_parity(got.cpu(), g["x_mean"], 1e-3, "pc sampler golden 3 steps")
 
 
 def test_em_sampler_matches_reference_golden(golden_dir):
@@ -100,7 +100,7 @@ def test_em_sampler_matches_reference_golden(golden_dir):
     net.eval()
     got = S.Euler_Maruyama_sampler(net, S.marginal_prob_std_fn, S.diffusion_coeff_fn, batch_size=2, num_steps=5, device="cuda",
                                    img_size=32, cond_img=g["cond_img"].cuda(), noise=g["noise"])
-    assert maxrel(got.cpu(), g["mean_x"]) <= 1e-3
+    check_parity(got.cpu(), g["mean_x"], 1e-3, "em sampler golden 5 steps")
 
 
 def test_cfg_guided_score_matches_reference_golden(golden_dir):
@@ -111,7 +111,7 @@ def test_cfg_guided_score_matches_reference_golden(golden_dir):
     with torch.no_grad():
         got = S.guided_score_fn(net, g["x"].cuda(), g["t"].cuda(), g["y"].cuda(), g["cond_img"].cuda(), g["lsm_cond"].cuda(),
                                 g["topo_cond"].cuda(), scale=1.5)
-    assert maxrel(got.cpu(), g["guided"]) <= TOL
+    check_parity(got.cpu(), g["guided"], TOL, "guided score golden")
 
 
 GUIDED = {"classifier_free_guidance": {"enabled": True, "guidance_scale": 2.5, "guidance_scale_max": 1.5}}
@@ -126,10 +126,10 @@ def test_guided_samplers_match_reference_goldens(golden_dir):
     kw = dict(y=g["y"].cuda(), cond_img=g["cond_img"].cuda(), lsm_cond=g["lsm_cond"].cuda(), topo_cond=g["topo_cond"].cuda(),
               cfg=GUIDED, device="cuda", batch_size=2, img_size=32)
     got = S.pc_sampler(net, S.marginal_prob_std_fn, S.diffusion_coeff_fn, num_steps=2, noise=g["noise"], **kw)
-    assert maxrel(got.cpu(), g["x_mean"]) <= 1e-3
+    check_parity(got.cpu(), g["x_mean"], 1e-3, "guided pc sampler golden")
     g = load_golden(os.path.join(golden_dir, "em_cfg_b2_32_3steps.npz"))
     got = S.Euler_Maruyama_sampler(net, S.marginal_prob_std_fn, S.diffusion_coeff_fn, num_steps=3, noise=g["noise"], **kw)
-    assert maxrel(got.cpu(), g["mean_x"]) <= 1e-3
+    check_parity(got.cpu(), g["mean_x"], 1e-3, "guided em sampler golden")
     # graph replay == eager launches, and the generic-callable Python loop (two evaluations + combine kernel) agrees
     a = S.pc_sampler(net, S.marginal_prob_std_fn, S.diffusion_coeff_fn, num_steps=3, seed=11, use_graph=True, **kw)
     b = S.pc_sampler(net, S.marginal_prob_std_fn, S.diffusion_coeff_fn, num_steps=3, seed=11, use_graph=False, **kw)

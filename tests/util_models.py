@@ -26,3 +26,31 @@ def load_golden(path):
 
 def maxrel(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def elemrel(a, b):
+    """element-wise relative error with a floor of 1e-3 of the tensor's scale: max |a - b| / (|b| + 1e-3 max|b|).  Beside the global
+    norm above it bounds a LOCALISED error on small-magnitude outputs (a score where |s| << max|s|), which max|a-b| / max|b| hides."""
+    b = b.to(a.dtype)
+    return float(((a - b).abs() / (b.abs() + 1e-3 * b.abs().max().clamp_min(1e-30))).max())
+
+
+_MEASURED = {}
+
+
+def check_parity(got, want, tol, label, elem_tol=None):
+    """global-norm max-rel <= tol AND element-wise (floored) relative error <= elem_tol (default 20 x tol); both printed and kept in
+    gpurun_out/measured_parity.json so the bounds can be read against data"""
+    import json
+    import os
+    g, e = maxrel(got, want), elemrel(got, want)
+    print(f"parity[{label}]: global max-rel {g:.2e} (tol {tol:.0e}), element-wise {e:.2e}")
+    _MEASURED[label] = {"global": g, "elementwise": e}
+    try:
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        json.dump(_MEASURED, open(os.path.join(d, "measured_parity.json"), "w"), indent=1, sort_keys=True)
+    except OSError:
+        pass
+    assert g <= tol, (label, g)
+    assert e <= (elem_tol if elem_tol is not None else 20 * tol), (label, e)
