@@ -171,7 +171,8 @@ def _overlap_main(rank, world, port, out_dir):
             assert bucket.copies == 0
         train_graph.set_overlap_bucket(None)
         assert early == {"single": 0, "overlap": 1}
-        # atomically accumulated gradients differ between two backward passes by summation order; everything else is bit-equal
+        # two backward passes: the atomically accumulated weight gradients differ in the last bit by summation order, so the two
+        # exchanges are compared to rounding (the bit-for-bit statement is the CPU test, where both run on ONE backward's gradients)
         same = float((flats["single"] == flats["overlap"]).float().mean())
         err = maxrel(flats["overlap"], flats["single"])
         if rank == 0:
@@ -184,4 +185,4 @@ def test_overlapped_gradient_exchange_equals_single_all_reduce(tmp_path):
     mp.spawn(_overlap_main, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
     got = torch.load(tmp_path / "overlap.pt", weights_only=True)
     print("overlapped vs single all-reduce: identical elements", got["same"], "max-rel", got["err"])
-    assert got["err"] < 1e-5 and got["same"] > 0.5
+    assert got["err"] < 1e-5
