@@ -119,23 +119,27 @@ def usable_cores():
     return n, how
 
 
-def cpu_baseline(batch, hw, budget_s=20.0):
-    """Oracle on the host cores: 1 warm-up + as many Euler-Maruyama steps as fit the budget (at least 2)."""
+def cpu_baseline(batch, hw, budget_s=20.0, sampler="em", n_cond=1, max_steps=50):
+    """Oracle on the host cores: 1 warm-up + as many SDE steps as fit the budget (at least 2).  sampler "pc" = 2 evaluations per step
+    (corrector + predictor, reference score_sampling.py:136-230), "em" = 1."""
     from oracle import torch_ref as O
     cores, how = usable_cores()
     torch.set_num_threads(cores)
     torch.manual_seed(42)
-    ora = O.build_scorenet(1).eval()
-    x, c = torch.randn(batch, 1, hw, hw), torch.randn(batch, 1, hw, hw)
+    ora = O.build_scorenet(n_cond).eval()
+    x = torch.randn(batch, 1, hw, hw)
+    c = torch.randn(batch, n_cond, hw, hw) if n_cond else None
     t = torch.full((batch,), 0.5)
+    evals = 2 if sampler == "pc" else 1
     with torch.no_grad():
         ora(x, t, cond_img=c)
         n, t0 = 0, time.perf_counter()
         while n < 2 or (time.perf_counter() - t0) < budget_s * 0.6:
-            s = ora(x, t, cond_img=c)
-            x = x + 1e-3 * s + 0.03 * torch.randn_like(x)
+            for _ in range(evals):
+                s = ora(x, t, cond_img=c)
+                x = x + 1e-3 * s + 0.03 * torch.randn_like(x)
             n += 1
-            if n >= 50:
+            if n >= max_steps:
                 break
         dt = time.perf_counter() - t0
     model = ""
@@ -144,9 +148,164 @@ def cpu_baseline(batch, hw, budget_s=20.0):
             model = next(l.split(":", 1)[1].strip() for l in f if l.startswith("model name"))
     except Exception:
         pass
+    name = "Euler-Maruyama" if sampler == "em" else "predictor-corrector"
     return {"value": batch * n / dt, "unit": "denoising steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n} Euler-Maruyama steps of the CPU oracle at batch {batch}, {hw}x{hw}, after 1 warm-up "
+            "sample": f"{n} {name} steps of the CPU oracle at batch {batch}, {hw}x{hw}, after 1 warm-up "
                       f"({dt:.1f} s, PyTorch-CPU {torch.__version__}, {model}; threads = {how})"}
+
+
+def sampling_secondary(dev, B, HW, sampler_key, steps, warmup, n_cond=1):
+    """another BASELINE sampling configuration beside the headline (C4: 256x256, batch 16, predictor-corrector; C1: 64x64, one
+    sample, no condition): same timing rules as the headline, its own autotune and its own roofline block"""
+    import sbgm_danra_amd as S
+    net = build_model(dev, n_cond=n_cond)
+    g = torch.Generator().manual_seed(42)
+    cond = torch.randn(B, n_cond, HW, HW, generator=g).to(dev) if n_cond else None
+    net.autotune(B, HW, HW, cond_channels=(0, 0, n_cond))
+    sampler = S.Euler_Maruyama_sampler if sampler_key == "em" else S.pc_sampler
+    evals = 1 if sampler_key == "em" else 2
+    kw = dict(batch_size=B, device=dev, img_size=HW, cond_img=cond, use_graph=True, seed=1234)
+    sampler(net, S.marginal_prob_std_fn, S.diffusion_coeff_fn, num_steps=max(2, warmup), **kw)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = sampler(net, S.marginal_prob_std_fn, S.diffusion_coeff_fn, num_steps=steps, **kw)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert torch.isfinite(out).all()
+    roof = conv_roofline(net, cond, B, HW, sampler_key, dt / (steps * evals) * 1e3, dev) if n_cond else None
+    return {"value": B * steps / dt, "unit": "denoising steps/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
+            "network_evals_per_s": B * steps * evals / dt,
+            "workload": f"{HW}x{HW}, C_in={1 + n_cond}, batch {B}, {'Euler-Maruyama' if sampler_key == 'em' else 'predictor-corrector'} "
+                        f"({evals} network eval/step), hipGraph on", "roofline": roof}
+
+
+def domain_secondary(dev, steps, warmup):
+    """BASELINE configs[4] on one GPU: a 589x789 field as 12 tiles of 256x256 (halo 32), predictor-corrector, stitched"""
+    import sbgm_danra_amd as S
+    from sbgm_danra_amd.tiling import FullDomainTiler
+    net = build_model(dev)
+    tiler = FullDomainTiler((589, 789), 256, 32, device=dev)
+    net.autotune(len(tiler), 256, 256, cond_channels=(0, 0, 1))
+    g = torch.Generator().manual_seed(42)
+    cond = torch.randn(1, 589, 789, generator=g).to(dev)
+    run = lambda n: tiler.sample(net, S.pc_sampler, S.marginal_prob_std_fn, S.diffusion_coeff_fn, num_steps=n, cond_img=cond, seed=7)   # noqa: E731
+    run(max(2, warmup))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = run(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert out.shape == (1, 589, 789) and torch.isfinite(out).all()
+    flops_step = 2 * FLOP_PER_SAMPLE_128 * len(tiler) * 4.0                     # 2 evaluations of 12 tiles of 256x256 per SDE step
+    return {"value": len(tiler) * steps / dt, "unit": "tile denoising steps/s", "ms_per_step": dt / steps * 1e3, "steps": steps,
+            "warmup": warmup, "tiles": len(tiler), "seconds_per_500_step_field": dt / steps * 500,
+            "workload": "589x789 domain, 12 tiles of 256x256 (halo 32), predictor-corrector, tile extraction + stitch included",
+            "whole_step": {"gflop": flops_step * 1e-9, "fp32_frac": flops_step / (dt / steps) / (PEAK_FP32_TFLOPS * 1e12)}}
+
+
+def conv_roofline(net, cond, B, HW, sampler_key, ms_eval_in, dev, profile_csv=None):
+    """Roofline of the dominant convolution kernel family of one network evaluation at (B, HW): every convolution launch bracketed
+    by HIP events on the launch stream (sbgm_model_profile_forward), grouped by kernel function as `rocprofv3 --stats` does; HBM
+    traffic from the committed PMC passes of the same workload when they were measured on these kernel sources."""
+    from sbgm_danra_amd import _native as N
+    lib = N.lib()
+    x = torch.randn(B, 1, HW, HW, device=dev) * 10
+    t = torch.full((B,), 0.5, device=dev)
+    o = torch.empty_like(x)
+    eng = net._engine(None, None, cond)
+    prof = N.Profile()
+    best = None
+    import csv
+    import tempfile
+    csv_path = profile_csv or os.path.join(tempfile.gettempdir(), f"sbgm_conv_profile_{os.getpid()}.csv")
+    for _ in range(5):
+        N.check(lib.sbgm_model_profile_forward(eng.h, x.data_ptr(), t.data_ptr(), None, cond.data_ptr(), None, None,
+                                               o.data_ptr(), B, HW, HW, C.byref(prof), csv_path.encode(), N.stream()))
+        if best is None or prof.ms_conv < best[0]:
+            with open(csv_path) as f:
+                rows = list(csv.DictReader(f))
+            best = (prof.ms_conv, prof.flops_conv, prof.n_conv, prof.ms_total_with_events, prof.ms_conv_max,
+                    prof.flops_conv_max, rows)
+    ms_conv, fl_conv, n_conv, ms_tot, ms_max, fl_max, rows = best
+    if not profile_csv:
+        os.unlink(csv_path)
+    # group the launches by kernel instantiation, the way `rocprofv3 --stats` does (profiles/r01_bench_kernel_stats.csv)
+    per = {}
+    for r in rows:
+        k = per.setdefault(r["kernel"].replace(";", ","), {"launches": 0, "ms": 0.0, "gflop": 0.0, "bytes": 0.0})
+        k["launches"] += 1
+        k["ms"] += float(r["ms"])
+        k["gflop"] += float(r["gflop"])
+        # algorithmic bytes of a launch: input once + output once + weights once (fp32)
+        cin, cout, kk = int(r["Cin_pad"]), int(r["Cout"]), int(r["kh"]) * int(r["kw"])
+        k["bytes"] += 4.0 * (int(r["B"]) * int(r["H"]) * int(r["W"]) * cin + int(r["M"]) * cout + kk * cin * cout)
+    kernels = [{"kernel": n, "launches": v["launches"], "avg_us": 1e3 * v["ms"] / v["launches"],
+                "gflop_per_launch": v["gflop"] / v["launches"], "tflops": v["gflop"] / v["ms"],
+                "alg_bytes_per_launch": v["bytes"] / v["launches"]}
+               for n, v in sorted(per.items(), key=lambda kv: -kv[1]["ms"])]
+    for k in kernels:        # Winograd instantiations execute 2/3 (F(2,3) along rows) or 4/9 (F(2x2,3x3)) of the algorithmic (direct-convolution) FLOPs as MFMAs
+        wino = "wino_kernel" in k["kernel"] or ("lds_kernel" in k["kernel"] and k["kernel"].split(",")[2].strip() == "true")
+        k["executed_flop_ratio"] = 4.0 / 9.0 if "w2d" in k["kernel"] else (2.0 / 3.0 if wino else 1.0)      # F(2x2,3x3): 4 of 9
+    # The dominant kernel = the kernel FUNCTION (template) with the largest share of an evaluation; the autotuner spreads its
+    # launches over several instantiations (tile / Winograd / double-buffer arguments), listed under "instantiations" with
+    # the names `rocprofv3 --stats` prints, so the two can be compared row by row.
+    fam = {}
+    for k in kernels:
+        f = fam.setdefault(k["kernel"].split("<")[0], {"launches": 0, "us": 0.0, "gflop": 0.0, "bytes": 0.0, "exec": 0.0, "inst": []})
+        f["launches"] += k["launches"]
+        f["us"] += k["avg_us"] * k["launches"]
+        f["gflop"] += k["gflop_per_launch"] * k["launches"]
+        f["bytes"] += k["alg_bytes_per_launch"] * k["launches"]
+        f["exec"] += k["gflop_per_launch"] * k["launches"] * k["executed_flop_ratio"]
+        f["inst"].append(k)
+    dname, df = max(fam.items(), key=lambda kv: kv[1]["us"])
+    dom = {"kernel": dname + "<...>", "launches": df["launches"], "avg_us": df["us"] / df["launches"],
+           "gflop_per_launch": df["gflop"] / df["launches"], "tflops": df["gflop"] / df["us"] * 1e3,
+           "alg_bytes_per_launch": df["bytes"] / df["launches"], "executed_flop_ratio": df["exec"] / df["gflop"],
+           "instantiations": df["inst"]}
+    # HBM-side traffic of that kernel: PMC counters cannot be read from inside this process; they come from the separately
+    # collected rocprofv3 passes of THIS workload (tools/collect_profiles.sh -> profiles/<round>_pmc_traffic_<workload>.json).
+    # A file measured on other kernel sources (source_hash) is refused: traffic = null with the reason.
+    traffic, traffic_src = None, None
+    wl = f"b{B}_{HW}_{sampler_key}"
+    for tag in ("r06", "r05", "r04", "r03", "r02"):
+        tp = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic_{wl}.json")
+        if not os.path.exists(tp):
+            continue
+        with open(tp) as f:
+            tj = json.load(f)
+        if tj.get("source_hash") != kernel_source_hash():
+            traffic_src = f"refused profiles/{tag}_pmc_traffic_{wl}.json: measured on kernel sources {tj.get('source_hash')}, this tree is {kernel_source_hash()}"
+            break
+        ents = [(v["bytes_per_launch"], v["launches"]) for n, v in tj["kernels"].items() if n.split("<")[0] == dname]
+        if ents:
+            traffic = sum(b * n for b, n in ents) / sum(n for _, n in ents)
+            traffic_src = f"profiles/{tag}_pmc_traffic_{wl}.json (2*FETCH_SIZE + WRITE_SIZE per launch, launch-weighted over the instantiations; same kernel sources)"
+        break
+    if traffic_src is None:
+        traffic_src = f"no profiles/*_pmc_traffic_{wl}.json for this workload"
+    ach = fl_conv / (ms_conv * 1e-3) * 1e-12
+    ms_eval = ms_eval_in
+    flops_eval = FLOP_PER_SAMPLE_128 * B * (HW / 128.0) ** 2
+    # top level = the single kernel instantiation with the largest share of an evaluation; `conv_family` = all convolution
+    # launches of one evaluation (3 kernel templates, fp32 v_mfma_f32_16x16x4_f32); `kernels` = every instantiation.
+    roof = {"bound": "mfma", "kernel": dom["kernel"], "launches_per_eval": dom["launches"], "avg_launch_us": dom["avg_us"],
+            "gflop_per_launch": dom["gflop_per_launch"],
+            "achieved": dom["tflops"], "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_FP32_TFLOPS,
+            # `achieved` counts the algorithmic (direct-convolution) FLOPs of SURVEY 8d; a Winograd F(2,3) kernel issues 2/3 of
+            # them, so the matrix pipe itself is busy for about frac * executed_flop_ratio of the time
+            "executed_flop_ratio": dom["executed_flop_ratio"],
+            "mfma_pipe_frac": dom["tflops"] * dom["executed_flop_ratio"] / PEAK_FP32_TFLOPS,
+            "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
+            "alg_bytes_per_launch": dom["alg_bytes_per_launch"], "instantiations": dom["instantiations"],
+            "conv_family": {"launches": n_conv, "ms_per_eval": ms_conv, "gflop_per_eval": fl_conv * 1e-9, "achieved": ach,
+                            "frac": ach / PEAK_FP32_TFLOPS},
+            "slowest_launch": {"ms": ms_max, "tflops": fl_max / (ms_max * 1e-3) * 1e-12},
+            "kernels": kernels,
+            "whole_eval": {"ms": ms_eval, "gflop": flops_eval * 1e-9,
+                           "fp32_frac": flops_eval / (ms_eval * 1e-3) / (PEAK_FP32_TFLOPS * 1e12),
+                           "hbm_frac_layer_fused_bytes": BYTES_PER_EVAL(B, HW) / (ms_eval * 1e-3) / (PEAK_HBM_GBS * 1e9)}}
+    return roof
 
 
 def train_secondary(dev, steps=10, warmup=3):
@@ -458,115 +617,33 @@ def main():
 
     roof, cpu = None, None
     if rank == 0:
-        # ---- roofline of the dominant kernel family, HIP events on the launch stream -------------------------------
-        lib = N.lib()
-        x = torch.randn(B, 1, HW, HW, device=dev) * 10
-        t = torch.full((B,), 0.5, device=dev)
-        o = torch.empty_like(x)
-        eng = net._engine(None, None, cond)
-        prof = N.Profile()
-        best = None
-        import csv
-        import tempfile
-        csv_path = a.profile_csv or os.path.join(tempfile.gettempdir(), f"sbgm_conv_profile_{os.getpid()}.csv")
-        for _ in range(5):
-            N.check(lib.sbgm_model_profile_forward(eng.h, x.data_ptr(), t.data_ptr(), None, cond.data_ptr(), None, None,
-                                                   o.data_ptr(), B, HW, HW, C.byref(prof), csv_path.encode(), N.stream()))
-            if best is None or prof.ms_conv < best[0]:
-                with open(csv_path) as f:
-                    rows = list(csv.DictReader(f))
-                best = (prof.ms_conv, prof.flops_conv, prof.n_conv, prof.ms_total_with_events, prof.ms_conv_max,
-                        prof.flops_conv_max, rows)
-        ms_conv, fl_conv, n_conv, ms_tot, ms_max, fl_max, rows = best
-        if not a.profile_csv:
-            os.unlink(csv_path)
-        # group the launches by kernel instantiation, the way `rocprofv3 --stats` does (profiles/r01_bench_kernel_stats.csv)
-        per = {}
-        for r in rows:
-            k = per.setdefault(r["kernel"].replace(";", ","), {"launches": 0, "ms": 0.0, "gflop": 0.0, "bytes": 0.0})
-            k["launches"] += 1
-            k["ms"] += float(r["ms"])
-            k["gflop"] += float(r["gflop"])
-            # algorithmic bytes of a launch: input once + output once + weights once (fp32)
-            cin, cout, kk = int(r["Cin_pad"]), int(r["Cout"]), int(r["kh"]) * int(r["kw"])
-            k["bytes"] += 4.0 * (int(r["B"]) * int(r["H"]) * int(r["W"]) * cin + int(r["M"]) * cout + kk * cin * cout)
-        kernels = [{"kernel": n, "launches": v["launches"], "avg_us": 1e3 * v["ms"] / v["launches"],
-                    "gflop_per_launch": v["gflop"] / v["launches"], "tflops": v["gflop"] / v["ms"],
-                    "alg_bytes_per_launch": v["bytes"] / v["launches"]}
-                   for n, v in sorted(per.items(), key=lambda kv: -kv[1]["ms"])]
-        for k in kernels:        # Winograd F(2,3) instantiations execute 2/3 of the algorithmic (direct-convolution) FLOPs as MFMAs
-            wino = "wino_kernel" in k["kernel"] or ("lds_kernel" in k["kernel"] and k["kernel"].split(",")[2].strip() == "true")
-            k["executed_flop_ratio"] = 2.0 / 3.0 if wino else 1.0
-        # The dominant kernel = the kernel FUNCTION (template) with the largest share of an evaluation; the autotuner spreads its
-        # launches over several instantiations (tile / Winograd / double-buffer arguments), listed under "instantiations" with
-        # the names `rocprofv3 --stats` prints, so the two can be compared row by row.
-        fam = {}
-        for k in kernels:
-            f = fam.setdefault(k["kernel"].split("<")[0], {"launches": 0, "us": 0.0, "gflop": 0.0, "bytes": 0.0, "exec": 0.0, "inst": []})
-            f["launches"] += k["launches"]
-            f["us"] += k["avg_us"] * k["launches"]
-            f["gflop"] += k["gflop_per_launch"] * k["launches"]
-            f["bytes"] += k["alg_bytes_per_launch"] * k["launches"]
-            f["exec"] += k["gflop_per_launch"] * k["launches"] * k["executed_flop_ratio"]
-            f["inst"].append(k)
-        dname, df = max(fam.items(), key=lambda kv: kv[1]["us"])
-        dom = {"kernel": dname + "<...>", "launches": df["launches"], "avg_us": df["us"] / df["launches"],
-               "gflop_per_launch": df["gflop"] / df["launches"], "tflops": df["gflop"] / df["us"] * 1e3,
-               "alg_bytes_per_launch": df["bytes"] / df["launches"], "executed_flop_ratio": df["exec"] / df["gflop"],
-               "instantiations": df["inst"]}
-        # HBM-side traffic of that kernel: PMC counters cannot be read from inside this process; they come from the separately
-        # collected rocprofv3 passes of THIS workload (tools/collect_profiles.sh -> profiles/<round>_pmc_traffic_<workload>.json).
-        # A file measured on other kernel sources (source_hash) is refused: traffic = null with the reason.
-        traffic, traffic_src = None, None
-        wl = f"b{B}_{HW}_{a.sampler}"
-        for tag in ("r06", "r05", "r04", "r03", "r02"):
-            tp = os.path.join(ROOT, "profiles", f"{tag}_pmc_traffic_{wl}.json")
-            if not os.path.exists(tp):
-                continue
-            with open(tp) as f:
-                tj = json.load(f)
-            if tj.get("source_hash") != kernel_source_hash():
-                traffic_src = f"refused profiles/{tag}_pmc_traffic_{wl}.json: measured on kernel sources {tj.get('source_hash')}, this tree is {kernel_source_hash()}"
-                break
-            ents = [(v["bytes_per_launch"], v["launches"]) for n, v in tj["kernels"].items() if n.split("<")[0] == dname]
-            if ents:
-                traffic = sum(b * n for b, n in ents) / sum(n for _, n in ents)
-                traffic_src = f"profiles/{tag}_pmc_traffic_{wl}.json (2*FETCH_SIZE + WRITE_SIZE per launch, launch-weighted over the instantiations; same kernel sources)"
-            break
-        if traffic_src is None:
-            traffic_src = f"no profiles/*_pmc_traffic_{wl}.json for this workload"
-        ach = fl_conv / (ms_conv * 1e-3) * 1e-12
-        ms_eval = dt / (a.steps * evals_per_step) * 1e3
-        flops_eval = FLOP_PER_SAMPLE_128 * B * (HW / 128.0) ** 2
-        # top level = the single kernel instantiation with the largest share of an evaluation; `conv_family` = all convolution
-        # launches of one evaluation (3 kernel templates, fp32 v_mfma_f32_16x16x4_f32); `kernels` = every instantiation.
-        roof = {"bound": "mfma", "kernel": dom["kernel"], "launches_per_eval": dom["launches"], "avg_launch_us": dom["avg_us"],
-                "gflop_per_launch": dom["gflop_per_launch"],
-                "achieved": dom["tflops"], "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": dom["tflops"] / PEAK_FP32_TFLOPS,
-                # `achieved` counts the algorithmic (direct-convolution) FLOPs of SURVEY 8d; a Winograd F(2,3) kernel issues 2/3 of
-                # them, so the matrix pipe itself is busy for about frac * executed_flop_ratio of the time
-                "executed_flop_ratio": dom["executed_flop_ratio"],
-                "mfma_pipe_frac": dom["tflops"] * dom["executed_flop_ratio"] / PEAK_FP32_TFLOPS,
-                "traffic": traffic, "traffic_unit": "bytes per launch", "traffic_source": traffic_src,
-                "alg_bytes_per_launch": dom["alg_bytes_per_launch"], "instantiations": dom["instantiations"],
-                "conv_family": {"launches": n_conv, "ms_per_eval": ms_conv, "gflop_per_eval": fl_conv * 1e-9, "achieved": ach,
-                                "frac": ach / PEAK_FP32_TFLOPS},
-                "slowest_launch": {"ms": ms_max, "tflops": fl_max / (ms_max * 1e-3) * 1e-12},
-                "kernels": kernels,
-                "whole_eval": {"ms": ms_eval, "gflop": flops_eval * 1e-9,
-                               "fp32_frac": flops_eval / (ms_eval * 1e-3) / (PEAK_FP32_TFLOPS * 1e12),
-                               "hbm_frac_layer_fused_bytes": BYTES_PER_EVAL(B, HW) / (ms_eval * 1e-3) / (PEAK_HBM_GBS * 1e9)}}
+        roof = conv_roofline(net, cond, B, HW, a.sampler, dt / (a.steps * evals_per_step) * 1e3, dev, a.profile_csv)
     secondary = None
     if rank == 0 and world == 1 and not a.no_secondary and B == 32 and HW == 128:
-        # BASELINE configs[2] beside the headline, so the training step is driver-timed too: per-GPU shape (batch 8, C_in = 5)
+        # the other BASELINE configurations beside the headline, driver-timed too (each in a try: never lose the headline line):
+        # configs[2] per-GPU training step, configs[3] 256x256 predictor-corrector, configs[4] full-domain tiles, configs[0] 64x64
         del net, out, cond
         torch.cuda.empty_cache()
-        try:
-            secondary = {"train_c3": train_secondary(dev)}
-        except Exception as e:                                     # never lose the headline line to the secondary measurement
-            secondary = {"train_c3": {"error": f"{type(e).__name__}: {e}"}}
+        secondary = {}
+        for name, fn in (("train_c3", lambda: train_secondary(dev)),
+                         ("c4_pc", lambda: sampling_secondary(dev, 16, 256, "pc", 10, 3)),
+                         ("c5_domain", lambda: domain_secondary(dev, 6, 2)),
+                         ("c1_em", lambda: sampling_secondary(dev, 1, 64, "em", 50, 5, n_cond=0))):
+            try:
+                secondary[name] = fn()
+            except Exception as e:
+                secondary[name] = {"error": f"{type(e).__name__}: {e}"}
+            torch.cuda.empty_cache()
     if rank == 0 and not a.no_cpu_baseline and world == 1:         # the CPU reference leg is reported at N=1 only; it runs LAST: its
         cpu = cpu_baseline(B, HW)                                  # OpenMP workers keep spinning on the host cores the GPU legs launch from
+        if secondary is not None:                                   # CPU evals/s for the other configurations as well
+            for name, args in (("c1_em", dict(batch=1, hw=64, budget_s=4.0, sampler="em", n_cond=0, max_steps=50)),
+                               ("c4_pc", dict(batch=16, hw=256, budget_s=10.0, sampler="pc", max_steps=5))):
+                try:
+                    if isinstance(secondary.get(name), dict):
+                        secondary[name]["cpu_baseline"] = cpu_baseline(**args)
+                except Exception as e:
+                    secondary[name]["cpu_baseline"] = {"error": f"{type(e).__name__}: {e}"}
 
     if rank == 0:
         value = B * a.steps * world / dt
