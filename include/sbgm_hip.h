@@ -71,6 +71,9 @@ int sbgm_model_set_param(sbgm_model* m, const char* name, const void* data, int6
 int sbgm_model_get_param(sbgm_model* m, const char* name, float* dst, int64_t numel, void* stream);
 /* 0 when every expected entry has been uploaded; otherwise an error naming the first missing one. */
 int sbgm_model_check_complete(const sbgm_model* m);
+/* Bytes of activation workspace the handle currently owns.  The first evaluation of a shape runs on a generous bound; later calls
+ * ask for the measured high-water mark and the surplus is returned (same addresses in the same order: bit-identical results). */
+int64_t sbgm_model_workspace_bytes(const sbgm_model* m);
 
 /* score = ScoreNet(x, t, y, cond_img, lsm_cond, topo_cond); out is NCHW [B,1,H,W].  Optional inputs may be NULL
  * when the model was configured with 0 channels for them.  bn_train != 0 uses batch statistics in the encoder's

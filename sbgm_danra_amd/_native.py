@@ -75,6 +75,7 @@ SIGNATURES = {
     "sbgm_model_set_param": (_i, [_vp, C.c_char_p, _vp, _i64, _vp]),
     "sbgm_model_get_param": (_i, [_vp, C.c_char_p, _vp, _i64, _vp]),
     "sbgm_model_check_complete": (_i, [_vp]),
+    "sbgm_model_workspace_bytes": (_i64, [_vp]),
     "sbgm_model_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, C.POINTER(_vp), _i, _i, _i, _i, _vp]),
     "sbgm_sampler_run": (_i, [_vp, C.POINTER(SamplerArgs), _vp]),
     "sbgm_pointwise_chain": (_i, [_vp, _vp, _i64, _i, C.POINTER(C.c_int), C.POINTER(C.c_float), _vp]),

@@ -3,6 +3,7 @@
 // hipGraph).  Mirrors, at the launch-sequence level, reference sbgm/score_unet.py:247-364 (Encoder.forward),
 // :559-627 (DecoderBlock.forward), :733-758 (Decoder.forward), :829-879 (ScoreNet.forward) and
 // sbgm/score_sampling.py:63-127 / :136-230.
+#include <array>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -182,19 +183,35 @@ struct sbgm_model {
     }
     float* partial = nullptr;           // split-K scratch shared by every convolution of a forward (stream-ordered reuse)
     static constexpr size_t PARTIAL_FLOATS = 16u << 20;   // 64 MiB
-    size_t fwd_need(int B, int H, int W) const;
+    // Workspace sizing.  The first evaluation of a (B, H, W, BatchNorm mode) runs on a generous bound (1 Ki floats per input pixel);
+    // its bump-allocator high-water mark is recorded and every later call asks for exactly that (+ 8 MiB), and ensure_ws gives the
+    // surplus back once every shape seen so far is measured (C2: 2.2 GB -> ~0.45 GB).  Addresses are assigned in the same order
+    // either way, so results are bit-identical.
+    std::map<std::array<int, 4>, size_t> ws_peak;
+    size_t ws_target = 0;                   // largest measured total need (forward + sampler slabs) of any shape seen so far
+    size_t fwd_need(int B, int H, int W, int bn_train = 0) const;
     size_t sampler_keep(int B, int H, int W) const {
         const size_t n = (size_t)B * H * W;
         return align_up(n * 4, 256) * 3 + align_up((size_t)B * 4, 256) + align_up((size_t)B * 8, 256);
     }
-    size_t ws_need(int B, int H, int W) const { return fwd_need(B, H, W) + sampler_keep(B, H, W); }
+    size_t ws_need(int B, int H, int W, int bn_train = 0) const { return fwd_need(B, H, W, bn_train) + sampler_keep(B, H, W); }
     int fold_bn(hipStream_t st);
     ConvTile pick_tile(const ConvGeom& g, const ConvParams& p);
     int conv(const ConvGeom& g, ConvParams p, hipStream_t st);
     int launch_any(const ConvGeom& g, ConvParams p, const ConvTile& ct, hipStream_t st) { return launch_tile(g, p, ct, partial, st); }
     int attention(const AttnW& a, float* x, int B, int S, hipStream_t st);
+    int forward_impl(const float* x, const float* t, const int64_t* y, const float* cond, const float* lsm, const float* topo,
+                     float* out, float* const* fmaps_out, int B, int H, int W, int bn_train, hipStream_t st);
     int forward(const float* x, const float* t, const int64_t* y, const float* cond, const float* lsm, const float* topo,
-                float* out, float* const* fmaps_out, int B, int H, int W, int bn_train, hipStream_t st);
+                float* out, float* const* fmaps_out, int B, int H, int W, int bn_train, hipStream_t st) {
+        const int rc = forward_impl(x, t, y, cond, lsm, topo, out, fmaps_out, B, H, W, bn_train, st);
+        if (!rc && !tuning) {                                // the evaluation's high-water mark sizes every later call of this shape
+            size_t& pk = ws_peak[std::array<int, 4>{B, H, W, bn_train != 0}];
+            pk = std::max(pk, ws_used);
+            ws_target = std::max(ws_target, pk + ((size_t)8 << 20) + sampler_keep(B, H, W));
+        }
+        return rc;
+    }
     int sampler(const sbgm_sampler_args& a, hipStream_t st);
 };
 
@@ -333,7 +350,11 @@ int sbgm_model::build(const sbgm_model_config& c) {
 }
 
 int sbgm_model::ensure_ws(size_t bytes) {
-    if (bytes <= ws_bytes) return 0;
+    // enough, and not grossly oversized now that every shape in use has a measured need: keep it
+    const bool trim = ws != nullptr && ws_target > 0 && bytes <= ws_bytes &&
+                      ws_bytes > std::max(bytes, ws_target) + ((size_t)256 << 20);
+    if (bytes <= ws_bytes && !trim) return 0;
+    if (trim) bytes = std::max(bytes, ws_target);
     drop_step_graph();                       // its nodes point into the old workspace
     if (ws) SBGM_HIP(hipFree(ws));
     ws = nullptr; ws_bytes = 0;
@@ -342,8 +363,10 @@ int sbgm_model::ensure_ws(size_t bytes) {
     return 0;
 }
 
-// generous upper bound: every intermediate gets its own slab (no liveness reuse yet)
-size_t sbgm_model::fwd_need(int B, int H, int W) const {
+// measured high-water mark of this shape when there is one, else a generous upper bound
+size_t sbgm_model::fwd_need(int B, int H, int W, int bn_train) const {
+    auto it = ws_peak.find(std::array<int, 4>{B, H, W, bn_train != 0});
+    if (it != ws_peak.end()) return it->second + ((size_t)8 << 20);
     const size_t px = (size_t)B * H * W;
     // NHWC floats per input pixel summed over all intermediates (encoder ~ 64/4*3 + ..., decoder dominated by the
     // final block's 3 x 64 channels at full resolution); 1024 floats/pixel is > 2x the true footprint.
@@ -588,9 +611,9 @@ int sbgm_model::attention(const AttnW& a, float* x, int B, int S, hipStream_t st
     return conv(lin, p, st);
 }
 
-int sbgm_model::forward(const float* x, const float* t, const int64_t* y, const float* cond, const float* lsm,
-                        const float* topo, float* out, float* const* fmaps_out, int B, int H, int W, int bn_train,
-                        hipStream_t st) {
+int sbgm_model::forward_impl(const float* x, const float* t, const int64_t* y, const float* cond, const float* lsm,
+                             const float* topo, float* out, float* const* fmaps_out, int B, int H, int W, int bn_train,
+                             hipStream_t st) {
     SBGM_CHECK(B >= 1 && H >= 32 && W >= 32 && H % 32 == 0 && W % 32 == 0,
                "forward: H,W must be positive multiples of 32 (five stride-2 stages), got B=%d H=%d W=%d", B, H, W);
     SBGM_CHECK(x && t && out, "forward: x, t and out are required");
@@ -600,7 +623,7 @@ int sbgm_model::forward(const float* x, const float* t, const int64_t* y, const 
     SBGM_CHECK(!(y && !label_emb), "forward: y given but the model has no label embedding");
     if (sbgm_model_check_complete(this)) return 1;
     if (!tuning) {
-        SBGM_CHECK(fwd_need(B, H, W) <= ws_bytes, "forward: workspace not prepared for B=%d H=%d W=%d", B, H, W);
+        SBGM_CHECK(fwd_need(B, H, W, bn_train) <= ws_bytes, "forward: workspace not prepared for B=%d H=%d W=%d", B, H, W);
         ws_used = 0;
     }
     if (bn_dirty && fold_bn(st)) return 1;
@@ -819,9 +842,10 @@ int sbgm_model::forward(const float* x, const float* t, const int64_t* y, const 
         if (ci == 64) {
             // conv_up's 64-channel output feeds only the linear 3x3 Cout=1 conv: project onto its 9 taps in the epilogue
             // (9 floats per pixel instead of 64) and finish with a 9-point gather.
+            p.proj_w = fin_conv.w->dev;
             float* d = wsalloc((size_t)9 * B * H * W * 4);      // up to 4 partial planes (2-D Winograd tiles of 16 channels)
             if (!d) return 1;
-            p.out = d; p.proj_w = fin_conv.w->dev; p.proj_out = d;
+            p.out = d; p.proj_out = d;
             if (conv(ConvGeom{3, 3, 1, 1}, p, st)) return 1;
             const int parts = last_tile.wino == 2 ? sbgm_conv_w2d_proj_parts(p, last_tile) : 1;
             if (sbgm_launch_tap_stencil(d, fin_conv.b->dev, t, cfg.sigma, out, B, H, W, st, parts)) return 1;
@@ -868,7 +892,7 @@ int sbgm_model::sampler(const sbgm_sampler_args& a, hipStream_t caller) {
     const bool guided = a.cfg_enabled != 0;
     const int BE = guided ? 2 * B : B;                     // samples per network evaluation
     const size_t per = (size_t)H * W, n = (size_t)B * per;
-    SBGM_CHECK(ws_need(BE, H, W) <= ws_bytes, "sampler: workspace not prepared for B=%d H=%d W=%d", BE, H, W);
+    SBGM_CHECK(ws_need(BE, H, W, a.bn_train) <= ws_bytes, "sampler: workspace not prepared for B=%d H=%d W=%d", BE, H, W);
     // ---- per-step scalars on the host, in the reference's precision --------------------------------------------------
     std::vector<StepScalars> tab(N);
     const float sig = cfg.sigma;
@@ -1099,6 +1123,8 @@ int sbgm_model_get_param(sbgm_model* m, const char* name, float* dst, int64_t nu
     return 0;
 }
 
+int64_t sbgm_model_workspace_bytes(const sbgm_model* m) { return (int64_t)m->ws_bytes; }
+
 int sbgm_model_check_complete(const sbgm_model* m) {
     for (auto& p : m->params) SBGM_CHECK(p->filled, "model: state_dict entry '%s' was never uploaded", p->name.c_str());
     return 0;
@@ -1107,13 +1133,13 @@ int sbgm_model_check_complete(const sbgm_model* m) {
 int sbgm_model_forward(sbgm_model* m, const float* x, const float* t, const int64_t* y, const float* cond_img,
                        const float* lsm_cond, const float* topo_cond, float* out, float* const* fmaps, int B, int H, int W,
                        int bn_train, void* stream) {
-    if (m->ensure_ws(m->ws_need(B, H, W))) return 1;
+    if (m->ensure_ws(m->ws_need(B, H, W, bn_train))) return 1;
     return m->forward(x, t, y, cond_img, lsm_cond, topo_cond, out, fmaps, B, H, W, bn_train, (hipStream_t)stream);
 }
 
 int sbgm_sampler_run(sbgm_model* m, const sbgm_sampler_args* a, void* stream) {
     SBGM_CHECK(a, "sampler_run: null args");
-    if (m->ensure_ws(m->ws_need(a->cfg_enabled ? 2 * a->B : a->B, a->H, a->W))) return 1;
+    if (m->ensure_ws(m->ws_need(a->cfg_enabled ? 2 * a->B : a->B, a->H, a->W, a->bn_train))) return 1;
     return m->sampler(*a, (hipStream_t)stream);
 }
 

@@ -399,3 +399,27 @@ def test_replaced_submodule_is_seen_by_the_engine():
         net.decoder.residual_layers[3] = new_block           # a different module object with different weights
         y1 = net(x, t, cond_img=c)
     assert maxrel(y1.cpu(), y0.cpu()) > 1e-3
+
+
+def test_workspace_is_trimmed_to_the_measured_high_water_mark():
+    """C2 shape (B = 32, 128x128): the first evaluation runs on the generous bound (1 Ki floats per input pixel = 2.2 GB), later calls
+    on the measured high-water mark; the handle must end below 0.6 GB and the outputs must not change by a bit"""
+    from sbgm_danra_amd import _native as N
+    _, net, _ = build_pair(1)
+    net.eval()
+    g = torch.Generator().manual_seed(8)
+    x, c = torch.randn(32, 1, 128, 128, generator=g).cuda(), torch.randn(32, 1, 128, 128, generator=g).cuda()
+    t = (torch.rand(32, generator=g) * 0.9 + 0.05).cuda()
+    sizes, outs = [], []
+    with torch.no_grad():
+        for _ in range(3):
+            outs.append(net(x, t, cond_img=c).clone())
+            sizes.append(N.lib().sbgm_model_workspace_bytes(net._engine(None, None, c).h))
+    print("workspace bytes after calls 1..3:", sizes)
+    assert sizes[0] > 2e9 and sizes[-1] < 0.6e9
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    # a sampler run at the same shape still fits (its persistent slabs sit on top of the evaluation's share)
+    import sbgm_danra_amd as S
+    s = S.Euler_Maruyama_sampler(net, S.marginal_prob_std_fn, S.diffusion_coeff_fn, batch_size=32, num_steps=3, device="cuda", img_size=128,
+                                 cond_img=c, seed=3)
+    assert torch.isfinite(s).all() and N.lib().sbgm_model_workspace_bytes(net._engine(None, None, c).h) < 0.6e9
