@@ -219,7 +219,8 @@ int sbgm_conv2d_tune(const sbgm_conv_args* a, int* tile, void* stream);
  * transposed bit 0 packs the data-gradient operator: then Cout/Cin are the TRANSPOSED sizes (Cout = forward Cin, Cin = forward
  * Cout) and cs is the padded forward Cout, exactly as sbgm_conv_pack_weight_dgrad does for one weight.
  * transposed bit 1 (3x3 kernels, cs %% 16 == 0, Cout %% 16 == 0): dst is the Winograd image U[kh][cs/16][xi][Cout][16] of
- * sbgm_conv_wino_pack_weight (sbgm_conv_wino_packed_numel floats) of that operator instead; nsteps is ignored. */
+ * sbgm_conv_wino_pack_weight (sbgm_conv_wino_packed_numel floats) of that operator instead; nsteps is ignored.
+ * transposed bit 2 (same conditions): dst is the F(2x2,3x3) image of sbgm_conv_wino2d_pack_weight (sbgm_conv_wino2d_packed_numel). */
 typedef struct sbgm_pack_desc {
     const float* src;      /* OIHW */
     float* dst;            /* packed [nsteps][Cout][16] */
@@ -378,6 +379,11 @@ int sbgm_conv3x3_cout1_bwd(const float* dout, const float* a, const float* w_tap
                            float* dw_tap_c, float* dbias, int B, int H, int W, int C, void* stream);
 int sbgm_time_proj_bwd(const float* dout, const float* weight, const float* semb, const float* emb_raw, float* dW,
                        float* dbias, float* demb_accum /* NULL or [B,D], accumulated */, int B, int D, int ch, void* stream);
+/* dW / dbias of up to 16 projections in one launch (HOST arrays of device pointers; projection i: douts[i] [B, chs[i]], sembs[i] [B, D]
+ * = silu(embedding) it read, dWs[i] [chs[i], D], dbiases[i] [chs[i]]).  The embedding gradient (label embedding only) stays with
+ * sbgm_time_proj_bwd. */
+int sbgm_time_proj_multi_bwd(const float* const* douts, const float* const* sembs, float* const* dWs, float* const* dbiases,
+                             const int* chs, int n_proj, int B, int D, void* stream);
 int sbgm_label_emb_bwd(const float* demb, const int64_t* y, float* dtable, int B, int D, void* stream);
 int sbgm_act_fwd(const float* x, float* y, int64_t n, int act, void* stream);
 int sbgm_act_bwd(const float* x, const float* dy, float* dx, int64_t n, int act, void* stream);

@@ -144,6 +144,7 @@ SIGNATURES = {
     "sbgm_upsample2x_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "sbgm_conv3x3_cout1_bwd": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "sbgm_time_proj_bwd": (_i, [_vp] * 7 + [_i, _i, _i, _vp]),
+    "sbgm_time_proj_multi_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "sbgm_time_proj_multi_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
     "sbgm_label_emb_bwd": (_i, [_vp, _vp, _vp, _i, _i, _vp]),
     "sbgm_act_fwd": (_i, [_vp, _vp, _i64, _i, _vp]),

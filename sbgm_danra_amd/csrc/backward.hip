@@ -1080,6 +1080,32 @@ __global__ __launch_bounds__(256) void time_proj_bwd_w_kernel(const float* __res
         if (dd == 0) dbias[c] = sb;
     }
 }
+// the same for up to 16 projections in ONE launch (a training step has 9: 42 us of 4.7 us launches): block -> projection by prefix
+struct TimeProjBwdMulti {
+    const float* dout[16];
+    const float* semb[16];
+    float* dW[16];
+    float* dbias[16];
+    int ch[16];
+    int block_begin[17];
+    int n, B, D;
+};
+__global__ __launch_bounds__(256) void time_proj_bwd_w_multi_kernel(const TimeProjBwdMulti a) {
+    int k = 0;
+    while (k + 1 < a.n && a.block_begin[k + 1] <= (int)blockIdx.x) ++k;
+    const float* __restrict__ dout = a.dout[k];
+    const float* __restrict__ semb = a.semb[k];
+    const int ch = a.ch[k], D = a.D, B = a.B;
+    const size_t total = (size_t)ch * D;
+    const int nb = a.block_begin[k + 1] - a.block_begin[k];
+    for (size_t i = (size_t)(blockIdx.x - a.block_begin[k]) * blockDim.x + threadIdx.x; i < total; i += (size_t)nb * blockDim.x) {
+        const int dd = (int)(i % D), c = (int)(i / D);
+        float s = 0.f, sb = 0.f;
+        for (int b = 0; b < B; ++b) { const float g = dout[(size_t)b * ch + c]; s = fmaf(g, semb[(size_t)b * D + dd], s); sb += g; }
+        a.dW[k][i] = s;
+        if (dd == 0) a.dbias[k][c] = sb;
+    }
+}
 // demb_pre[b][d] (+)= silu'(emb) * sum_c dout[b][c] W[c][d]   (emb recovered from `emb_raw` = pre-SiLU embedding)
 __global__ __launch_bounds__(256) void time_proj_bwd_e_kernel(const float* __restrict__ dout, const float* __restrict__ Wt,
                                                               const float* __restrict__ emb_raw, float* __restrict__ demb, int B,
@@ -1422,6 +1448,24 @@ int sbgm_launch_time_proj_bwd(const float* dout, const float* weight, const floa
         hipLaunchKernelGGL(time_proj_bwd_e_kernel, dim3((B * D + 255) / 256), dim3(256), 0, st, dout, weight, emb_raw, demb_accum, B, D, ch);
         SBGM_LAUNCH_CHECK();
     }
+    return 0;
+}
+
+int sbgm_launch_time_proj_multi_bwd(const float* const* douts, const float* const* sembs, float* const* dWs, float* const* dbs, const int* chs,
+                                    int n_proj, int B, int D, hipStream_t st) {
+    SBGM_CHECK(n_proj >= 1 && n_proj <= 16, "time_proj_multi_bwd: n_proj=%d (1..16)", n_proj);
+    TimeProjBwdMulti a{};
+    a.n = n_proj; a.B = B; a.D = D;
+    int nb = 0;
+    for (int k = 0; k < n_proj; ++k) {
+        SBGM_CHECK(douts[k] && sembs[k] && dWs[k] && dbs[k] && chs[k] > 0, "time_proj_multi_bwd: null tensor in projection %d", k);
+        a.dout[k] = douts[k]; a.semb[k] = sembs[k]; a.dW[k] = dWs[k]; a.dbias[k] = dbs[k]; a.ch[k] = chs[k];
+        a.block_begin[k] = nb;
+        nb += (int)std::min<size_t>(((size_t)chs[k] * D + 255) / 256, 512);
+    }
+    a.block_begin[n_proj] = nb;
+    hipLaunchKernelGGL(time_proj_bwd_w_multi_kernel, dim3(nb), dim3(256), 0, st, a);
+    SBGM_LAUNCH_CHECK();
     return 0;
 }
 

@@ -303,6 +303,11 @@ int sbgm_time_proj_bwd(const float* dout, const float* weight, const float* semb
                        float* demb_accum, int B, int D, int ch, void* stream) {
     return sbgm_launch_time_proj_bwd(dout, weight, semb, emb_raw, dW, dbias, demb_accum, B, D, ch, ST);
 }
+int sbgm_time_proj_multi_bwd(const float* const* douts, const float* const* sembs, float* const* dWs, float* const* dbiases, const int* chs,
+                             int n_proj, int B, int D, void* stream) {
+    SBGM_CHECK(douts && sembs && dWs && dbiases && chs, "time_proj_multi_bwd: null argument");
+    return sbgm_launch_time_proj_multi_bwd(douts, sembs, dWs, dbiases, chs, n_proj, B, D, ST);
+}
 int sbgm_label_emb_bwd(const float* demb, const int64_t* y, float* dtable, int B, int D, void* stream) {
     return sbgm_launch_label_emb_bwd(demb, y, dtable, B, D, ST);
 }

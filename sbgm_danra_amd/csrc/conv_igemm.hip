@@ -332,6 +332,7 @@ __global__ __launch_bounds__(256) void pack_conv_weights_batched_kernel(const sb
     }
     sbgm_pack_desc d = desc[lo];
     const bool wino = (d.transposed & 2) != 0;               // validated on the host: 3x3, tiled
+    const bool w2d = (d.transposed & 4) != 0;                // F(2x2,3x3) image U[cb][xi*4+eta][Cout][16] (conv_w2d.hip), same validation
     d.transposed &= 1;
     const int rel = blockIdx.x - d.block_begin;
     if (!pack_tiled(d.Cout, d.cs, d.KH * d.KW)) {
@@ -354,6 +355,27 @@ __global__ __launch_bounds__(256) void pack_conv_weights_batched_kernel(const sb
     }
     __syncthreads();
     const int k16 = threadIdx.x & 15, col = threadIdx.x >> 4;   // destination: c = c0 + k16, co = co0 + col
+    if (w2d) {                                               // U = G g G^T: rows first, then columns (as pack_w2d_weight_kernel)
+        float rowv[4][3];
+#pragma unroll
+        for (int kw = 0; kw < 3; ++kw) {
+            float g[3];
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh) {
+                const int tap = kh * 3 + kw;
+                g[kh] = d.transposed ? pk[k16 * RS + col * Tp + (T - 1 - tap)] : pk[col * RS + k16 * Tp + tap];
+            }
+            rowv[0][kw] = g[0]; rowv[1][kw] = 0.5f * ((g[0] + g[1]) + g[2]); rowv[2][kw] = 0.5f * ((g[0] - g[1]) + g[2]); rowv[3][kw] = g[2];
+        }
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi) {
+            const float r0 = rowv[xi][0], r1 = rowv[xi][1], r2 = rowv[xi][2];
+            const float u[4] = {r0, 0.5f * ((r0 + r1) + r2), 0.5f * ((r0 - r1) + r2), r2};
+#pragma unroll
+            for (int eta = 0; eta < 4; ++eta) d.dst[((size_t)(cb * 16 + xi * 4 + eta) * d.Cout + co0) * 16 + threadIdx.x] = u[eta];
+        }
+        return;
+    }
     if (wino) {                                              // U[kh][cb][xi][Cout][16], U = G g along the filter row (conv_wino.hip)
         for (int kh = 0; kh < 3; ++kh) {
             float g[3];

@@ -264,6 +264,8 @@ int sbgm_launch_cout1_bwd(const float* dout, const float* a, const float* w_tap_
                           float* dw_tap_c, float* dbias, int B, int H, int W, int C, hipStream_t st);
 int sbgm_launch_time_proj_bwd(const float* dout, const float* weight, const float* semb, const float* emb_raw, float* dW, float* dbias,
                               float* demb_accum, int B, int D, int ch, hipStream_t st);
+int sbgm_launch_time_proj_multi_bwd(const float* const* douts, const float* const* sembs, float* const* dWs, float* const* dbs, const int* chs,
+                                    int n_proj, int B, int D, hipStream_t st);
 int sbgm_launch_label_emb_bwd(const float* demb, const int64_t* y, float* dtable, int B, int D, hipStream_t st);
 int sbgm_launch_act_bwd(const float* x, const float* dy, float* dx, size_t n, int act, hipStream_t st);
 int sbgm_launch_act_fwd(const float* x, float* y, size_t n, int act, hipStream_t st);

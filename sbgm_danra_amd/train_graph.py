@@ -255,14 +255,15 @@ class _PackPlan:
         self.owner = lambda: None
 
     def note(self, w, cs, dgrad, layout):
-        """layout 'g' / 'w': the tuned forward kernel of this call read the implicit-GEMM / the Winograd weight image.  One weight
+        """layout 'g' / 'w' / 'd': the tuned forward kernel of this call read the implicit-GEMM / the Winograd F(2,3) / the Winograd
+        F(2x2,3x3) weight image.  One weight
         may be needed in both (two batch shapes whose tuned tiles differ): every layout ever used is packed from then on."""
         key = (w.data_ptr(), cs)
         e = self.entries.get(key)
         if e is None:
             base = w._base if w._base is not None else w
             e = self.entries[key] = dict(shape=tuple(w.shape), cs=cs, dgrad=False, ref=weakref.ref(base), need=set(),
-                                         img={("fwd", "g"): None, ("fwd", "w"): None, ("bwd", "g"): None, ("bwd", "w"): None})
+                                         img={(r_, l_): None for r_ in ("fwd", "bwd") for l_ in ("g", "w", "d")})
             self.dirty = True
         if dgrad and not e["dgrad"]:
             e["dgrad"] = True
@@ -290,10 +291,12 @@ class _PackPlan:
             jobs = []
             for (role, layout) in sorted(e["need"]):
                 co_, ci_, cs_ = (cout, cin, cs) if role == "fwd" else (cin, cout, cso)
-                n = _L().sbgm_conv_wino_packed_numel(co_, cs_) if layout == "w" else _L().sbgm_conv_packed_numel(co_, k, k, cs_)
+                n = (_L().sbgm_conv_wino_packed_numel(co_, cs_) if layout == "w" else
+                     _L().sbgm_conv_wino2d_packed_numel(co_, cs_) if layout == "d" else _L().sbgm_conv_packed_numel(co_, k, k, cs_))
                 if e["img"][(role, layout)] is None:         # never re-allocated: a captured step keeps reading the image it saw
                     e["img"][(role, layout)] = torch.empty(n, device=dev)
-                jobs.append((e["img"][(role, layout)], co_, ci_, cs_, (1 if role == "bwd" else 0) | (2 if layout == "w" else 0)))
+                jobs.append((e["img"][(role, layout)], co_, ci_, cs_,
+                             (1 if role == "bwd" else 0) | (2 if layout == "w" else 0) | (4 if layout == "d" else 0)))
             e["packed"] = True
             for dst, co_, ci_, cs_, tr in jobs:
                 nsteps = dst.numel() // (co_ * 16)
@@ -334,46 +337,68 @@ def _wino_ok(k, stride, pad, in_dil, cs, cout, W):
     return k == 3 and stride == 1 and pad == 1 and not in_dil and cs % 16 == 0 and cout % 32 == 0 and W % 2 == 0
 
 
+def _w2d_ok(k, stride, pad, in_dil, cs, cout, H, W):
+    """geometries the 2-D Winograd F(2x2,3x3) kernels take (conv_w2d.hip: 16-pixel-wide tiles, 2x2 output blocks)"""
+    return k == 3 and stride == 1 and pad == 1 and not in_dil and cs % 16 == 0 and cout % 32 == 0 and W % 16 == 0 and H % 2 == 0
+
+
 class _MissingImage(Exception):
-    """the geometry's tuned tile reads a weight image ('g' implicit GEMM / 'w' Winograd) the caller did not bring"""
+    """the geometry's tuned tile reads a weight image ('g' implicit GEMM / 'w' Winograd F(2,3) / 'd' F(2x2,3x3)) the caller did not
+    bring"""
+
+
+def _tile_from_tune(t6):
+    """sbgm_conv2d_tune's tile[6] -> (tile_co, tile_px, splits, waves_per_tile, winograd bits) of sbgm_conv_args"""
+    if t6[4] == 2:                                           # F(2x2,3x3): bit 3; bit 4 = persistent form, bit 2 = two stage buffers
+        return (t6[0], 0, 0, t6[3], 8 | (16 if t6[5] == 3 else (4 if t6[5] == 2 else 0)))
+    return (t6[0], t6[1], t6[2], t6[3], t6[4] | (2 if t6[5] else 0) | (4 if t6[5] == 2 else 0))
+
+
+def _tile_layout(tile):
+    return "d" if tile[4] & 8 else ("w" if tile[4] & 1 else "g")
 
 
 def _conv_launch(x, packed, out, cs, cout, k, stride, pad, bias=None, res=None, tbias=None, in_dil=0, out_hw=(0, 0), wino=None,
-                 on_missing="default"):
+                 w2d=None, on_missing="default"):
     """One convolution through the per-op C ABI.  The first time a geometry is seen (outside graph capture) the library
     times its kernel / tile / split-K candidates on these very operands and the winner is reused from then on.
-    packed / wino: the implicit-GEMM and the Winograd weight image; either may be None when the geometry's tile is known to read
-    the other.  Returns True when the launch read the Winograd image."""
+    packed / wino / w2d: the implicit-GEMM, the Winograd F(2,3) and the Winograd F(2x2,3x3) weight image; any may be None when the
+    geometry's tile is known to read another.  Returns the layout the launch read: 'g', 'w' or 'd'."""
     B, H, W, _ = x.shape
-    # the key says whether Winograd candidates take part for this geometry: first-step calls then bring both images, so the
+    # the key says which Winograd candidates take part for this geometry: first-step calls then bring every image, so the
     # cached tile never depends on which caller tuned it
     wk = _USE_WINO[0] and _wino_ok(k, stride, pad, in_dil, cs, cout, W)
-    key = (B, H, W, cs, cout, k, stride, pad, in_dil, out_hw, bias is not None, res is not None, tbias is not None, wk)
+    dk = _USE_WINO[0] and _w2d_ok(k, stride, pad, in_dil, cs, cout, H, W)
+    key = (B, H, W, cs, cout, k, stride, pad, in_dil, out_hw, bias is not None, res is not None, tbias is not None, wk, dk)
     ws = _splitk_ws(x.device)
-    a = N.ConvArgs(x.data_ptr(), (packed if packed is not None else wino).data_ptr(), out.data_ptr(), None, N.ptr(bias), N.ptr(tbias),
+    first = packed if packed is not None else (wino if wino is not None else w2d)
+    a = N.ConvArgs(x.data_ptr(), first.data_ptr(), out.data_ptr(), None, N.ptr(bias), N.ptr(tbias),
                    N.ptr(res), B, H, W, cs, cout, k, k, stride, pad, N.NONE, 0, 0, 0, 0, 0, 0, in_dil, out_hw[0], out_hw[1],
-                   ws.data_ptr(), _SPLITK_FLOATS, 0, None, None, 0, N.ptr(wino) if wk else None)
+                   ws.data_ptr(), _SPLITK_FLOATS, 0, None, None, 0, N.ptr(wino) if wk else None, N.ptr(w2d) if dk else None)
+    have = {"g": packed is not None, "w": wino is not None, "d": w2d is not None}
     tile = _TILES.get(key)
-    if tile is None and cout % 32 == 0 and not torch.cuda.is_current_stream_capturing() and packed is not None and (wino is not None or not wk):
+    if tile is None and cout % 32 == 0 and not torch.cuda.is_current_stream_capturing() and packed is not None \
+            and (wino is not None or not wk) and (w2d is not None or not dk):
         t6 = (C.c_int * 6)()
         N.check(_L().sbgm_conv2d_tune(C.byref(a), t6, _st()))
-        tile = _TILES[key] = (t6[0], t6[1], t6[2], t6[3], t6[4] | (2 if t6[5] else 0) | (4 if t6[5] == 2 else 0))
-    if tile is not None and (tile[4] & 1) and wino is None and on_missing == "raise":
-        raise _MissingImage("w")
-    if tile is not None and ((tile[4] & 1) and wino is None or not (tile[4] & 1) and packed is None):
-        tile = None                                    # the tuned choice reads an image this call does not have: default tile
+        tile = _TILES[key] = _tile_from_tune(t6)
+    if tile is not None and not have[_tile_layout(tile)]:
+        if on_missing == "raise":
+            raise _MissingImage(_tile_layout(tile))
+        tile = None                                        # the tuned choice reads an image this call does not have: default tile
     if tile is not None:
         a.tile_co, a.tile_px, a.splits, a.waves_per_tile, a.winograd = tile
     elif packed is None:
         raise _MissingImage("g")
     N.check(_L().sbgm_conv2d_fwd(C.byref(a), _st()))
-    return bool(a.winograd & 1)
+    return _tile_layout(tile) if tile is not None else "g"
 
 
 def _pack_single(w, cout, cin, k, cs, flags):
-    """one weight through the batched pack entry (flags: bit 0 data-gradient operator, bit 1 Winograd image); first step only"""
-    wino = bool(flags & 2)
-    dst = torch.empty(_L().sbgm_conv_wino_packed_numel(cout, cs) if wino else _L().sbgm_conv_packed_numel(cout, k, k, cs), device=w.device)
+    """one weight through the batched pack entry (flags: bit 0 data-gradient operator, bit 1 Winograd F(2,3) image, bit 2 F(2x2,3x3)
+    image); first step only"""
+    dst = torch.empty(_L().sbgm_conv_wino_packed_numel(cout, cs) if flags & 2 else
+                      _L().sbgm_conv_wino2d_packed_numel(cout, cs) if flags & 4 else _L().sbgm_conv_packed_numel(cout, k, k, cs), device=w.device)
     d = N.PackDesc(w.data_ptr(), dst.data_ptr(), cout, cin, k, k, cs, dst.numel() // (cout * 16), flags, 0)
     dev = torch.frombuffer(bytearray(bytes(d)), dtype=torch.uint8).to(w.device)
     N.check(_L().sbgm_conv_pack_weights_batched(dev.data_ptr(), 1, _L().sbgm_conv_pack_weights_batched_blocks(cout, k, k, cs), _st()))
@@ -396,23 +421,26 @@ class ConvFn(torch.autograd.Function):
         if e is not None:                                    # packed by the step's batched launch, in the layout(s) its tiles read
             try:
                 used = _conv_launch(x, e["img"][("fwd", "g")], y, cs, cout, k, stride, pad, bias, res, tbias, wino=e["img"][("fwd", "w")],
-                                    on_missing="raise")
+                                    w2d=e["img"][("fwd", "d")], on_missing="raise")
             except _MissingImage:                            # another batch shape of the same weight wants the other layout
                 used = None
         if used is None:
             packed = torch.empty(_L().sbgm_conv_packed_numel(cout, k, k, cs), device=x.device)
             N.check(_L().sbgm_conv_pack_weight(w.data_ptr(), packed.data_ptr(), cout, cin, k, k, cs, _st()))
-            pw = None
-            if _USE_WINO[0] and _wino_ok(k, stride, pad, 0, cs, cout, W) and not torch.cuda.is_current_stream_capturing():
-                pw = _pack_single(w, cout, cin, k, cs, 2)
-            used = _conv_launch(x, packed, y, cs, cout, k, stride, pad, bias, res, tbias, wino=pw)
+            pw = pd = None
+            if _USE_WINO[0] and not torch.cuda.is_current_stream_capturing():
+                if _wino_ok(k, stride, pad, 0, cs, cout, W):
+                    pw = _pack_single(w, cout, cin, k, cs, 2)
+                if _w2d_ok(k, stride, pad, 0, cs, cout, H, W):
+                    pd = _pack_single(w, cout, cin, k, cs, 4)
+            used = _conv_launch(x, packed, y, cs, cout, k, stride, pad, bias, res, tbias, wino=pw, w2d=pd)
             base = w._base if w._base is not None else w
             if plan is not None and base.is_leaf and base.data_ptr() == w.data_ptr() and base.numel() == w.numel():
                 # a parameter or a reshaped view of one (nn.Linear weights), not a derived tensor: batch-pack it from the next step on
-                plan.note(w, cs, dgrad=x.requires_grad and cs == cin and cs % 32 == 0, layout="w" if used else "g")
+                plan.note(w, cs, dgrad=x.requires_grad and cs == cin and cs % 32 == 0, layout=used)
         ctx.save_for_backward(x, w, bias)
         ctx.geom = (stride, pad, bias is not None, res is not None, tbias is not None)
-        ctx.packed_bwd = (e["img"][("bwd", "g")], e["img"][("bwd", "w")]) if e is not None else None
+        ctx.packed_bwd = (e["img"][("bwd", "g")], e["img"][("bwd", "w")], e["img"][("bwd", "d")]) if e is not None else None
         ctx.plan = plan
         ctx.arena = _ACTIVE_ARENA[0]
         return y
@@ -444,22 +472,24 @@ class ConvFn(torch.autograd.Function):
             dx = torch.empty_like(x)
             dil = 2 if stride == 2 else 0
             used = None
-            if ctx.packed_bwd is not None and (ctx.packed_bwd[0] is not None or ctx.packed_bwd[1] is not None):
+            if ctx.packed_bwd is not None and any(im is not None for im in ctx.packed_bwd):
                 try:
                     used = _conv_launch(dy, ctx.packed_bwd[0], dx, cout, cin, k, 1, k - 1 - pad, in_dil=dil, out_hw=(H, W),
-                                        wino=ctx.packed_bwd[1], on_missing="raise")
+                                        wino=ctx.packed_bwd[1], w2d=ctx.packed_bwd[2], on_missing="raise")
                 except _MissingImage:
                     used = None
             if used is None:
                 packed = torch.empty(_L().sbgm_conv_packed_numel(cin, k, k, cout), device=x.device)
                 N.check(_L().sbgm_conv_pack_weight_dgrad(w.data_ptr(), packed.data_ptr(), cout, cin, k, k, _st()))
-                pw = None
-                if _USE_WINO[0] and _wino_ok(k, 1, k - 1 - pad, dil, cout, cin, dy.shape[2]) and cout % 16 == 0 \
-                        and not torch.cuda.is_current_stream_capturing():
-                    pw = _pack_single(w, cin, cout, k, cout, 3)
-                used = _conv_launch(dy, packed, dx, cout, cin, k, 1, k - 1 - pad, in_dil=dil, out_hw=(H, W), wino=pw)
+                pw = pd = None
+                if _USE_WINO[0] and cout % 16 == 0 and not torch.cuda.is_current_stream_capturing():
+                    if _wino_ok(k, 1, k - 1 - pad, dil, cout, cin, dy.shape[2]):
+                        pw = _pack_single(w, cin, cout, k, cout, 3)
+                    if _w2d_ok(k, 1, k - 1 - pad, dil, cout, cin, dy.shape[1], dy.shape[2]):
+                        pd = _pack_single(w, cin, cout, k, cout, 5)
+                used = _conv_launch(dy, packed, dx, cout, cin, k, 1, k - 1 - pad, in_dil=dil, out_hw=(H, W), wino=pw, w2d=pd)
                 if ctx.plan is not None:
-                    ctx.plan.note_bwd(w, cs, "w" if used else "g")
+                    ctx.plan.note_bwd(w, cs, used)
         want_db = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             if _WGRAD_LOG[0] is not None:
@@ -783,15 +813,21 @@ class TimeProjMultiFn(torch.autograd.Function):
         B, D = semb.shape[1], semb.shape[2]
         demb = torch.zeros(B, D, device=semb.device) if has_y else None          # only embedding 0 carries the label embedding
         dWs, dbs = [None] * n_proj, [None] * n_proj
-        for i, dout in enumerate(douts):
-            if dout is None:
-                continue
-            dout = dout.contiguous()
+        live = [i for i, d in enumerate(douts) if d is not None]
+        dcs = {i: douts[i].contiguous() for i in live}
+        for i in live:
             dWs[i], dbs[i] = _pgrad(ctx.arena, weights[i], False)[0], _pgrad(ctx.arena, biases[i], False)[0]
-            e = emb_index[i]
-            N.check(_L().sbgm_time_proj_bwd(dout.data_ptr(), weights[i].data_ptr(), semb[e].data_ptr(), raw[e].data_ptr(),
-                                            dWs[i].data_ptr(), dbs[i].data_ptr(), N.ptr(demb) if e == 0 else None, B, D,
-                                            weights[i].shape[0], _st()))
+        if live:                                             # every weight / bias gradient of the group in one launch
+            arr = lambda ts: (C.c_void_p * len(ts))(*[x.data_ptr() for x in ts])             # noqa: E731
+            N.check(_L().sbgm_time_proj_multi_bwd(arr([dcs[i] for i in live]), arr([semb[emb_index[i]] for i in live]),
+                                                  arr([dWs[i] for i in live]), arr([dbs[i] for i in live]),
+                                                  (C.c_int * len(live))(*[weights[i].shape[0] for i in live]), len(live), B, D, _st()))
+        if has_y:                                            # label-embedding gradient: embedding 0's projections only
+            for i in live:
+                if emb_index[i] == 0:
+                    tmpW, tmpb = torch.empty_like(weights[i]), torch.empty_like(biases[i])
+                    N.check(_L().sbgm_time_proj_bwd(dcs[i].data_ptr(), weights[i].data_ptr(), semb[0].data_ptr(), raw[0].data_ptr(),
+                                                    tmpW.data_ptr(), tmpb.data_ptr(), demb.data_ptr(), B, D, weights[i].shape[0], _st()))
         dtable = None
         if has_y:
             dtable, was_zero = _pgrad(ctx.arena, table, True)

@@ -237,6 +237,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w2d_kernel(const ConvParams p)
 #pragma unroll
         for (int i = 0; i < FCO; ++i) acc[tp][i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+#ifdef EXP_STAGGER
+    if ((blockIdx.x / EXP_STAGGER_DIV) & 1) {                  // de-phase the two workgroups of a CU by ~half a stage
+        for (int i = 0; i < EXP_STAGGER; ++i) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     // ---- prologue: stage 0 of the first tile --------------------------------------------------------------------------------
     set_poff(nt);
     slab_dma(0);
