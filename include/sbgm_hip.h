@@ -371,8 +371,11 @@ int sbgm_batchnorm_bwd_reduce(const float* x, const float* dy, const float* y, c
 int sbgm_batchnorm_bwd_apply(const float* x, const float* dy, const float* y, const float* gamma, const float* tbias_after,
                              const float* mean_rstd, int relu, float* dx, float* dres, float* dgamma, float* dbeta, const float* ws,
                              const float* sync_sums, double n_total, int B, int HW, int C, void* stream);
+/* dx_add [M,C] or NULL: added to dx (the gradient reaching x along its other consumer, e.g. the residual around the block) */
 int sbgm_layernorm_bwd(const float* x, const float* dy, const float* gamma, float* dx, float* dgamma, float* dbeta, int M,
-                       int C, float eps, void* stream);
+                       int C, float eps, const float* dx_add, void* stream);
+/* zero `bytes` (multiple of 4) of device memory with a kernel on `stream` (graph-capture safe; see common.h on hipMemsetAsync) */
+int sbgm_fill_zero(void* p, int64_t bytes, void* stream);
 int sbgm_mha_core_bwd(const float* qkv, const float* dout, float* dqkv, int B, int S, int C, int heads, void* stream);
 int sbgm_upsample2x_bwd(const float* dy, float* dx, int B, int H, int W, int C, void* stream);
 int sbgm_conv3x3_cout1_bwd(const float* dout, const float* a, const float* w_tap_c, const float* t, float sigma, float* da,

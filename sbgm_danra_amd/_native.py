@@ -139,7 +139,8 @@ SIGNATURES = {
     "sbgm_samplesum": (_i, [_vp, _vp, _i, _i, _i, _vp]),
     "sbgm_groupnorm_bwd": (_i, [_vp] * 14 + [_i, _i, _i, _i, _vp]),
     "sbgm_batchnorm_bwd": (_i, [_vp] * 6 + [_i] + [_vp] * 5 + [_i, _i, _i, _vp]),
-    "sbgm_layernorm_bwd": (_i, [_vp] * 6 + [_i, _i, _f, _vp]),
+    "sbgm_layernorm_bwd": (_i, [_vp] * 6 + [_i, _i, _f, _vp, _vp]),
+    "sbgm_fill_zero": (_i, [_vp, _i64, _vp]),
     "sbgm_mha_core_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "sbgm_upsample2x_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "sbgm_conv3x3_cout1_bwd": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

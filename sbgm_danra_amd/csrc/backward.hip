@@ -698,7 +698,7 @@ constexpr int LN_MAX_K = 16;     // C <= 1024
 __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                             const float* __restrict__ gamma, float* __restrict__ dx,
                                                             float* __restrict__ dgamma, float* __restrict__ dbeta, int M, int C,
-                                                            float eps, int rows_per_wave) {
+                                                            float eps, int rows_per_wave, const float* __restrict__ dx_add) {
     extern __shared__ float ln_red[];                   // [4 waves][2][C]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int row0 = (blockIdx.x * 4 + wave) * rows_per_wave, row1 = min(M, row0 + rows_per_wave);
@@ -727,7 +727,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
             const int c = lane + 64 * k;
             if (c < C) {
                 const float xh = (xr[c] - mean) * rstd, g = gr[c];
-                dx[(size_t)row * C + c] = rstd * (g * gamma[c] - a1 - xh * a2);
+                // dx_add: the gradient that reaches x along its other consumer (the residual connection around the attention
+                // half-block), summed here instead of in a pass of its own
+                dx[(size_t)row * C + c] = rstd * (g * gamma[c] - a1 - xh * a2) + (dx_add ? dx_add[(size_t)row * C + c] : 0.f);
                 pg[k] += g * xh;
                 pb[k] += g;
             }
@@ -1352,7 +1354,7 @@ int sbgm_launch_batchnorm_bwd(const float* x, const float* dy, const float* y, c
 }
 
 int sbgm_launch_layernorm_bwd(const float* x, const float* dy, const float* gamma, float* dx, float* dgamma, float* dbeta, int M, int C,
-                              float eps, hipStream_t st) {
+                              float eps, hipStream_t st, const float* dx_add) {
     SBGM_CHECK(C <= 64 * LN_MAX_K, "layernorm_bwd: C=%d > %d", C, 64 * LN_MAX_K);
     if (sbgm_scratch_prezeroed) {
     } else if (dbeta == dgamma + C) {                     // one [2][C] tensor: one memset
@@ -1363,7 +1365,7 @@ int sbgm_launch_layernorm_bwd(const float* x, const float* dy, const float* gamm
     }
     const int rpw = std::max(1, M / 1024);               // ~256 blocks of 4 waves
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((M + 4 * rpw - 1) / (4 * rpw)), dim3(256), (size_t)8 * C * sizeof(float), st, x, dy, gamma,
-                       dx, dgamma, dbeta, M, C, eps, rpw);
+                       dx, dgamma, dbeta, M, C, eps, rpw, dx_add);
     SBGM_LAUNCH_CHECK();
     return 0;
 }

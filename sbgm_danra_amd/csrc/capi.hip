@@ -286,8 +286,12 @@ int sbgm_batchnorm_bwd(const float* x, const float* dy, const float* y, const fl
     return sbgm_launch_batchnorm_bwd(x, dy, y, gamma, tbias_after, mean_rstd, relu, dx, dres, dgamma, dbeta, ws, B, HW, C, ST);
 }
 int sbgm_layernorm_bwd(const float* x, const float* dy, const float* gamma, float* dx, float* dgamma, float* dbeta, int M, int C,
-                       float eps, void* stream) {
-    return sbgm_launch_layernorm_bwd(x, dy, gamma, dx, dgamma, dbeta, M, C, eps, ST);
+                       float eps, const float* dx_add, void* stream) {
+    return sbgm_launch_layernorm_bwd(x, dy, gamma, dx, dgamma, dbeta, M, C, eps, ST, dx_add);
+}
+int sbgm_fill_zero(void* p, int64_t bytes, void* stream) {
+    SBGM_CHECK(p && bytes >= 0 && bytes % 4 == 0, "fill_zero: bytes=%lld must be a non-negative multiple of 4", (long long)bytes);
+    return bytes ? sbgm_zero_async(p, (size_t)bytes, ST) : 0;
 }
 int sbgm_mha_core_bwd(const float* qkv, const float* dout, float* dqkv, int B, int S, int C, int heads, void* stream) {
     return sbgm_launch_mha_core_bwd(qkv, dout, dqkv, B, S, C, heads, ST);

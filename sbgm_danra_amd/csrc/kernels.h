@@ -257,7 +257,7 @@ int sbgm_launch_batchnorm_bwd(const float* x, const float* dy, const float* y, c
                               const float* mr, int relu, float* dx, float* dres, float* dgamma, float* dbeta, float* s12_ws, int B,
                               int HW, int C, hipStream_t st);
 int sbgm_launch_layernorm_bwd(const float* x, const float* dy, const float* gamma, float* dx, float* dgamma, float* dbeta, int M, int C,
-                              float eps, hipStream_t st);
+                              float eps, hipStream_t st, const float* dx_add = nullptr);   // dx_add [M, C] or null: summed into dx
 int sbgm_launch_mha_core_bwd(const float* qkv, const float* dout, float* dqkv, int B, int S, int C, int heads, hipStream_t st);
 int sbgm_launch_upsample2x_bwd(const float* dy, float* dx, int B, int H, int W, int C, hipStream_t st);
 int sbgm_launch_cout1_bwd(const float* dout, const float* a, const float* w_tap_c, const float* t, float sigma, float* da,

@@ -37,6 +37,13 @@ _SPLITK = {}           # device -> split-K scratch (16 Mi floats), shared by eve
 _SPLITK_FLOATS = 16 << 20
 
 
+def _zero_(t):
+    """t.zero_() with the library's own kernel (no at::native fill on the hot path; capture-safe)"""
+    if t.numel():
+        N.check(_L().sbgm_fill_zero(t.data_ptr(), t.numel() * t.element_size(), _st()))
+    return t
+
+
 def _splitk_ws(dev):
     ws = _SPLITK.get(dev)
     if ws is None:
@@ -66,10 +73,10 @@ def _zero_reset(dev):
     z[4] = z[4] or capturing               # replays of captured steps dirty the pool behind Python's back: from then on the
     dirty = z[2] if z[4] else z[1]         # whole high-water prefix is re-zeroed, not just this process's last step
     if dirty:
-        z[0][:dirty].zero_()
+        _zero_(z[0][:dirty])
     z[3] = z[2] if capturing else _ZERO_FLOATS
     z[1] = 0
-    _GRAD[dev] = [torch.zeros(_GRAD_FLOATS, device=dev), 0]
+    _GRAD[dev] = [_zero_(torch.empty(_GRAD_FLOATS, device=dev)), 0]
 
 
 # ---- gradient arena ------------------------------------------------------------------------------------------------------
@@ -96,7 +103,7 @@ class GradArena:
         return tuple(p.data_ptr() for p in net.parameters() if p.requires_grad)
 
     def begin_step(self):
-        self.flat.zero_()
+        _zero_(self.flat)
         self.claimed.clear()
 
     def view(self, t):
@@ -146,6 +153,77 @@ def _pgrad(arena, like, zeroed):
 # pre-activation within rounding distance of zero otherwise routes its gradient differently in two arithmetics, and one such flip
 # moves an encoder weight gradient by ~1e-2.
 _RELU_TRACE = [None]
+
+# ---- gradient slots ------------------------------------------------------------------------------------------------------
+# A forward tensor with several consumers (the residual forks of the BasicBlocks and attention half-blocks, the feature maps that
+# feed both the next encoder layer and a decoder skip) receives the SUM of its consumers' gradients.  Left to autograd that is one
+# at::native add launch per fork (20 per training step, ~5 us each at batch 8).  A slot lets the consumers sum inside their own
+# backward kernels: every consumer's backward takes the partial sum collected so far, folds it into its own kernel (the data
+# gradient convolution adds it in its epilogue as a residual, LayerNorm's backward takes it as dx_add) and either parks the new
+# partial sum in the slot (returning None to autograd) or, when it is the last consumer, returns the total.  Consumers may run in
+# any order; an incomplete slot at the end of the backward pass raises.
+class _GradSlot:
+    __slots__ = ("n", "left", "acc")
+
+    def __init__(self, n):
+        self.n, self.left, self.acc = n, n, None
+
+    def take(self, like=None):
+        a, self.acc = self.acc, None
+        return a if (a is None or like is None) else a.view(like.shape)
+
+    def give(self, g):
+        _queue_slot_check()
+        self.left -= 1
+        if self.left > 0:
+            self.acc = g
+            return None
+        self.left = self.n                                   # re-armed: a second backward over a retained graph works the same way
+        return g
+
+
+_SLOTS = []
+_SLOT_CHECK_QUEUED = [False]
+
+
+def _queue_slot_check():
+    if not _SLOT_CHECK_QUEUED[0]:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(_check_slots)
+            _SLOT_CHECK_QUEUED[0] = True
+        except RuntimeError:                                 # not inside a backward pass
+            pass
+_USE_SLOTS = [True]            # debugging switch: False = every fork summed by autograd (the pre-slot behaviour)
+
+
+def _slot(n):
+    if not _USE_SLOTS[0] or n < 2:
+        return None
+    sl = _GradSlot(n)
+    _SLOTS.append(sl)
+    return sl
+
+
+def _check_slots():
+    _SLOT_CHECK_QUEUED[0] = False
+    bad = [sl for sl in _SLOTS if sl.left != sl.n]           # untouched (no consumer needed the gradient) or completed: fine
+    for sl in bad:
+        sl.left, sl.acc = sl.n, None
+    if bad:
+        raise RuntimeError(f"{len(bad)} gradient slot(s) were left incomplete by the backward pass: a consumer of a shared tensor did not "
+                           f"run its backward (partial graph?); set train_graph._USE_SLOTS[0] = False")
+
+
+def _fold(slot, g, fused=False):
+    """hand gradient `g` of a slotted input to the slot; `fused`: the pending partial sum was already added by the kernel"""
+    if slot is None:
+        return g
+    if not fused:
+        extra = slot.take(g)
+        if extra is not None:
+            g = g + extra                                    # consumer without a fused-add path ran late: one torch add
+    return slot.give(g)
+
 
 # SyncBatchNorm (DESIGN.md 7): statistics summed over the ranks of the process group, see BNTrainFn
 _SYNC_BN = [False]
@@ -410,7 +488,7 @@ class ConvFn(torch.autograd.Function):
     Also serves nn.Linear as a 1x1 conv."""
 
     @staticmethod
-    def forward(ctx, x, w, bias, res, tbias, stride, pad):
+    def forward(ctx, x, w, bias, res, tbias, stride, pad, xslot=None, rslot=None):
         B, H, W, cs = x.shape
         cout, cin, k, _ = w.shape
         plan = _ACTIVE_PLAN[0]
@@ -440,6 +518,7 @@ class ConvFn(torch.autograd.Function):
                 plan.note(w, cs, dgrad=x.requires_grad and cs == cin and cs % 32 == 0, layout=used)
         ctx.save_for_backward(x, w, bias)
         ctx.geom = (stride, pad, bias is not None, res is not None, tbias is not None)
+        ctx.slots = (xslot, rslot)
         ctx.packed_bwd = (e["img"][("bwd", "g")], e["img"][("bwd", "w")], e["img"][("bwd", "d")]) if e is not None else None
         ctx.plan = plan
         ctx.arena = _ACTIVE_ARENA[0]
@@ -454,6 +533,9 @@ class ConvFn(torch.autograd.Function):
         B, H, W, cs = x.shape
         cout, cin, k, _ = w.shape
         dx = dw = db = None
+        xslot, rslot = ctx.slots
+        extra = xslot.take(x) if (xslot is not None and ctx.needs_input_grad[0]) else None      # partial sum from x's other consumers
+        fused = False
         if ctx.needs_input_grad[0] and k == 8 and stride == 2 and pad == 3 and cs == cin and cin % 16 == 0 and cout % 16 == 0 \
                 and H % 2 == 0 and W % 2 == 0:
             # stem conv2: phase-decomposed data gradient (5x5 / stride 1 over dy to 4*Cin phase-major channels + depth->space)
@@ -474,7 +556,7 @@ class ConvFn(torch.autograd.Function):
             used = None
             if ctx.packed_bwd is not None and any(im is not None for im in ctx.packed_bwd):
                 try:
-                    used = _conv_launch(dy, ctx.packed_bwd[0], dx, cout, cin, k, 1, k - 1 - pad, in_dil=dil, out_hw=(H, W),
+                    used = _conv_launch(dy, ctx.packed_bwd[0], dx, cout, cin, k, 1, k - 1 - pad, res=extra, in_dil=dil, out_hw=(H, W),
                                         wino=ctx.packed_bwd[1], w2d=ctx.packed_bwd[2], on_missing="raise")
                 except _MissingImage:
                     used = None
@@ -487,9 +569,10 @@ class ConvFn(torch.autograd.Function):
                         pw = _pack_single(w, cin, cout, k, cout, 3)
                     if _w2d_ok(k, 1, k - 1 - pad, dil, cout, cin, dy.shape[1], dy.shape[2]):
                         pd = _pack_single(w, cin, cout, k, cout, 5)
-                used = _conv_launch(dy, packed, dx, cout, cin, k, 1, k - 1 - pad, in_dil=dil, out_hw=(H, W), wino=pw, w2d=pd)
+                used = _conv_launch(dy, packed, dx, cout, cin, k, 1, k - 1 - pad, res=extra, in_dil=dil, out_hw=(H, W), wino=pw, w2d=pd)
                 if ctx.plan is not None:
                     ctx.plan.note_bwd(w, cs, used)
+            fused = True                                         # the convolution's epilogue added the pending partial sum
         want_db = has_bias and ctx.needs_input_grad[2]
         if ctx.needs_input_grad[1]:
             if _WGRAD_LOG[0] is not None:
@@ -523,14 +606,21 @@ class ConvFn(torch.autograd.Function):
             dtb = dtb.view(B, cout)
             with _prezeroed(zeroed):
                 N.check(_L().sbgm_samplesum(dy.data_ptr(), dtb.data_ptr(), B, dy.numel() // (B * cout), cout, _st()))
-        return dx, dw, db, (dy if has_res and ctx.needs_input_grad[3] else None), dtb, None, None
+        if xslot is not None and ctx.needs_input_grad[0]:
+            if not fused and extra is not None:
+                dx = dx + extra                                  # stem convolution (phase-decomposed data gradient): no residual epilogue
+            dx = xslot.give(dx)
+        dres = dy if has_res and ctx.needs_input_grad[3] else None
+        if dres is not None:
+            dres = _fold(rslot, dres)
+        return dx, dw, db, dres, dtb, None, None, None, None
 
 
-def linear(x2d, w, b, res=None):
+def linear(x2d, w, b, res=None, rslot=None):
     """nn.Linear over tokens [M, C] (+ residual) on the conv kernel"""
     M, Cc = x2d.shape
     y = ConvFn.apply(x2d.view(1, 1, M, Cc), w.view(w.shape[0], w.shape[1], 1, 1), b,
-                     None if res is None else res.view(1, 1, M, -1), None, 1, 0)
+                     None if res is None else res.view(1, 1, M, -1), None, 1, 0, None, rslot)
     return y.view(M, -1)
 
 
@@ -541,8 +631,9 @@ class BNTrainFn(torch.autograd.Function):
     single-device step on the GLOBAL batch (reference score_unet.py:323 sees the whole batch on one device)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, rm, rv, res, tb_after, relu, eps, momentum):
+    def forward(ctx, x, gamma, beta, rm, rv, res, tb_after, relu, eps, momentum, rslot=None):
         B, H, W, Cc = x.shape
+        ctx.rslot = rslot
         y = torch.empty_like(x)
         mr = torch.empty(Cc, 2, device=x.device)         # (mean, rstd) per channel, kept for the backward
         sums, pooled = _zeros(4 * Cc, x.device)          # 2C fp64 sums: scratch of this launch only
@@ -599,15 +690,16 @@ class BNTrainFn(torch.autograd.Function):
             dtb = dtb.view(B, Cc)
             with _prezeroed(zeroed):
                 N.check(_L().sbgm_samplesum(dy.data_ptr(), dtb.data_ptr(), B, H * W, Cc, _st()))
-        return dx, dg, db, None, None, dres, dtb, None, None, None
+        return dx, dg, db, None, None, (_fold(ctx.rslot, dres) if dres is not None else None), dtb, None, None, None, None
 
 
 class GroupNormFn(torch.autograd.Function):
     """y = act(GroupNorm(x) [+ skip] [+ tbias])   (gamma/beta None = InstanceNorm2d without affine)"""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, skip, tbias, act, G, eps):
+    def forward(ctx, x, gamma, beta, skip, tbias, act, G, eps, sslot=None):
         B, H, W, Cc = x.shape
+        ctx.sslot = sslot
         y = torch.empty_like(x)
         ws = torch.empty(1024 * B * G, dtype=torch.uint8, device=x.device)
         mr = torch.empty(B * G * 2, device=x.device)
@@ -635,16 +727,17 @@ class GroupNormFn(torch.autograd.Function):
             N.check(_L().sbgm_groupnorm_bwd(x.data_ptr(), dy.data_ptr(), N.ptr(gamma), N.ptr(beta), N.ptr(skip), N.ptr(tbias), mr.data_ptr(),
                                             act, dx.data_ptr(), N.ptr(dskip), N.ptr(dg), N.ptr(db), N.ptr(dtb), s12.data_ptr(), B, H * W, Cc,
                                             G, _st()))
-        return dx, dg, db, dskip, dtb, None, None, None
+        return dx, dg, db, (_fold(ctx.sslot, dskip) if dskip is not None else None), dtb, None, None, None, None
 
 
 class LayerNormFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, gamma, beta, eps):
+    def forward(ctx, x, gamma, beta, eps, xslot=None):
         M, Cc = x.shape
         y = torch.empty_like(x)
         N.check(_L().sbgm_layernorm_fwd(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), M, Cc, eps, _st()))
         ctx.save_for_backward(x, gamma, beta)
+        ctx.xslot = xslot
         ctx.eps = eps
         ctx.arena = _ACTIVE_ARENA[0]
         return y
@@ -661,10 +754,13 @@ class LayerNormFn(torch.autograd.Function):
         if not zeroed:                                   # adjacent: the launcher zeroes both with one memset
             dgb = torch.empty(2 * Cc, device=x.device)
             dg, db = dgb[:Cc], dgb[Cc:]
+        extra = ctx.xslot.take(x) if ctx.xslot is not None else None
         with _prezeroed(zeroed):
             N.check(_L().sbgm_layernorm_bwd(x.data_ptr(), dy.data_ptr(), gamma.data_ptr(), dx.data_ptr(), dg.data_ptr(), db.data_ptr(), M,
-                                            Cc, ctx.eps, _st()))
-        return dx, dg, db, None
+                                            Cc, ctx.eps, N.ptr(None if extra is None else extra.contiguous()), _st()))
+        if ctx.xslot is not None:
+            dx = ctx.xslot.give(dx)
+        return dx, dg, db, None, None
 
 
 class MHACoreFn(torch.autograd.Function):
@@ -882,10 +978,10 @@ def _pack_inputs(x, lsm, topo, cond, cs):
 _NBT = []
 
 
-def _bn(x, bn, res=None, tb_after=None, relu=True):
+def _bn(x, bn, res=None, tb_after=None, relu=True, rslot=None):
     if not bn.training:
-        return _bn_eval(x, bn, res, tb_after, relu)
-    y = BNTrainFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, res, tb_after, relu, bn.eps, bn.momentum)
+        return _bn_eval(x, bn, res, tb_after, relu, rslot)
+    y = BNTrainFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, res, tb_after, relu, bn.eps, bn.momentum, rslot)
     _NBT.append(bn.num_batches_tracked)                  # incremented together at the end of forward_train (one launch, not 20)
     return y
 
@@ -898,8 +994,9 @@ class BNEvalFn(torch.autograd.Function):
     on x), dgamma = sum g * xhat, dbeta = sum g."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, rm, rv, res, tb_after, relu, eps):
+    def forward(ctx, x, gamma, beta, rm, rv, res, tb_after, relu, eps, rslot=None):
         B, H, W, Cc = x.shape
+        ctx.rslot = rslot
         n = float(B * H * W)
         rmd, rvd = rm.double(), rv.double()
         ws = torch.empty(3 * Cc, dtype=torch.float64, device=x.device)              # (sum x, sum x^2) pairs + room for (mean, rstd)
@@ -938,24 +1035,27 @@ class BNEvalFn(torch.autograd.Function):
             dtb = dtb.view(B, Cc)
             with _prezeroed(zeroed):
                 N.check(_L().sbgm_samplesum(dy.data_ptr(), dtb.data_ptr(), B, H * W, Cc, _st()))
-        return dx, dg, db, None, None, dres, dtb, None, None
+        return dx, dg, db, None, None, (_fold(ctx.rslot, dres) if dres is not None else None), dtb, None, None, None
 
 
-def _bn_eval(x, bn, res, tb_after, relu):
+def _bn_eval(x, bn, res, tb_after, relu, rslot=None):
     """BatchNorm2d with running statistics (module.eval())"""
-    return BNEvalFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, res, tb_after, relu, bn.eps)
+    return BNEvalFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, res, tb_after, relu, bn.eps, rslot)
 
 
 def _attention(mod, x):                               # x: [B, H, W, C] -> same (reference score_unet.py:136-148)
     B, H, W, Cc = x.shape
     tok = x.reshape(B * H * W, Cc)
-    n1 = LayerNormFn.apply(tok, mod.ln1.weight, mod.ln1.bias, mod.ln1.eps)
+    grad = torch.is_grad_enabled() and tok.requires_grad
+    s1 = _slot(2) if grad else None                          # tok feeds ln1 and the residual of out_proj
+    n1 = LayerNormFn.apply(tok, mod.ln1.weight, mod.ln1.bias, mod.ln1.eps, s1)
     qkv = linear(n1, mod.mha.in_proj_weight, mod.mha.in_proj_bias)
     att = MHACoreFn.apply(qkv, B, H * W, Cc, mod.n_heads)
-    h = linear(att, mod.mha.out_proj.weight, mod.mha.out_proj.bias, res=tok)
-    n2 = LayerNormFn.apply(h, mod.ln2.weight, mod.ln2.bias, mod.ln2.eps)
+    h = linear(att, mod.mha.out_proj.weight, mod.mha.out_proj.bias, res=tok, rslot=s1)
+    s2 = _slot(2) if grad else None                          # h feeds ln2 and the residual of ff[2]
+    n2 = LayerNormFn.apply(h, mod.ln2.weight, mod.ln2.bias, mod.ln2.eps, s2)
     f = ActFn.apply(linear(n2, mod.ff[0].weight, mod.ff[0].bias), N.GELU)
-    return linear(f, mod.ff[2].weight, mod.ff[2].bias, res=h).view(B, H, W, Cc)
+    return linear(f, mod.ff[2].weight, mod.ff[2].bias, res=h, rslot=s2).view(B, H, W, Cc)
 
 
 def forward_train(net, x, t, y, cond, lsm, topo):
@@ -967,6 +1067,7 @@ def forward_train(net, x, t, y, cond, lsm, topo):
             del _PLANS[k]
     _ACTIVE_PLAN[0] = plan
     _NBT.clear()
+    _SLOTS.clear()
     _zero_reset(x.device)
     arena = None
     if _USE_ARENA[0] and all(p.grad is None for p in net.parameters()):      # fresh step: gradients go straight into the model's flat arena
@@ -980,8 +1081,9 @@ def forward_train(net, x, t, y, cond, lsm, topo):
         _SYNC_COUNT[0] = int(round(float(cnt.item())))
     plan.run(x.device)
     try:
-        fmaps = encoder_forward(net.encoder, x, t, y, cond, lsm, topo)
-        a = decoder_forward(net.decoder, fmaps, t)
+        skip_slots = []
+        fmaps = encoder_forward(net.encoder, x, t, y, cond, lsm, topo, skip_slots)
+        a = decoder_forward(net.decoder, fmaps, t, skip_slots)
         fin = net.decoder.final_layer
         _bump_nbt()
         return Cout1Fn.apply(a, fin.conv.weight, fin.conv.bias, t, float(net.sigma))
@@ -1001,8 +1103,10 @@ def _tproj(t, y, tlabel, freq_mod, seq):
     return TimeProjFn.apply(t, y, tlabel, freq_mod.W, seq[1].weight, seq[1].bias)
 
 
-def encoder_forward(enc, x, t, y, cond, lsm, topo):
-    """Encoder.forward (reference score_unet.py:247-364) on NCHW inputs -> the 5 feature maps, NHWC"""
+def encoder_forward(enc, x, t, y, cond, lsm, topo, skip_slots=None):
+    """Encoder.forward (reference score_unet.py:247-364) on NCHW inputs -> the 5 feature maps, NHWC.
+    skip_slots: a list that receives one gradient slot (or None) per feature map 0..3 when the CALLER will consume each map exactly
+    once more (the decoder's skip connections in forward_train); None: the maps' gradients are summed by autograd."""
     tlabel = enc.label_emb.weight if (y is not None and enc.num_classes is not None) else None
     if y is not None and tlabel is None:
         raise ValueError("y given but the model has no label embedding")
@@ -1010,21 +1114,35 @@ def encoder_forward(enc, x, t, y, cond, lsm, topo):
     seqs = [enc.time_projection_layers[i][1] for i in range(5)]               # one embedding, five SiLU -> Linear heads (:301-308)
     tb = TimeProjMultiFn.apply(t, y if tlabel is not None else None, tlabel, (0,) * 5, 1, enc.sinusoidal_embedding.W,
                                *[q.weight for q in seqs], *[q.bias for q in seqs])
+    grad = torch.is_grad_enabled()
+    shared = grad and skip_slots is not None
     f1 = ConvFn.apply(x0, enc.conv1.weight, None, None, tb[0], 2, 3)                    # conv1 + time bias (:312-316)
-    h = _bn(ConvFn.apply(f1, enc.conv2.weight, None, None, None, 2, 3), enc.bn1)
-    fmaps = [f1]
+    s_f1 = _slot(2) if shared else None                                                 # f1 feeds conv2 and the last decoder skip
+    h = _bn(ConvFn.apply(f1, enc.conv2.weight, None, None, None, 2, 3, s_f1), enc.bn1)
+    fmaps, slots = [f1], [s_f1]
+    hs = None                                # slot of `h` when it is a feature map the decoder consumes as well
     for li in range(1, 5):
         layer = getattr(enc, f"layer{li}")
         for bi, blk in enumerate(layer):
-            y1 = _bn(ConvFn.apply(h, blk.conv1.weight, None, None, None, blk.stride, 1), blk.bn1)
-            idn = h
+            # h feeds conv1 and either the shortcut convolution or the residual add (and, as a feature map, a decoder skip)
+            sx = hs if hs is not None else (_slot(2) if grad else None)
+            hs = None
+            y1 = _bn(ConvFn.apply(h, blk.conv1.weight, None, None, None, blk.stride, 1, sx), blk.bn1)
+            idn, rs = h, sx
             if blk.downsample is not None:
-                idn = _bn(ConvFn.apply(h, blk.downsample[0].weight, None, None, None, blk.stride, 0), blk.downsample[1], relu=False)
+                idn = _bn(ConvFn.apply(h, blk.downsample[0].weight, None, None, None, blk.stride, 0, sx), blk.downsample[1], relu=False)
+                rs = None
             last = bi == len(layer) - 1
-            h = _bn(ConvFn.apply(y1, blk.conv2.weight, None, None, None, 1, 1), blk.bn2, res=idn, tb_after=tb[li] if last else None)
+            h = _bn(ConvFn.apply(y1, blk.conv2.weight, None, None, None, 1, 1), blk.bn2, res=idn, tb_after=tb[li] if last else None,
+                    rslot=rs)
         if not isinstance(enc.attention_layers[li], torch.nn.Identity):
             h = _attention(enc.attention_layers[li], h)
         fmaps.append(h)
+        if li < 4:
+            hs = _slot(3) if shared else None
+            slots.append(hs)
+    if skip_slots is not None:
+        skip_slots[:] = slots
     return fmaps
 
 
@@ -1034,7 +1152,7 @@ def _upsampled(blk, h):           # (A) of DecoderBlock: resize-conv (default) o
     return conv_transpose2x(h, blk.transpose)
 
 
-def decoder_block_forward(blk, cur, skip, t, tbd=None):
+def decoder_block_forward(blk, cur, skip, t, tbd=None, sslot=None):
     """DecoderBlock.forward (reference score_unet.py:559-627) for a block WITH norms: NHWC in, NHWC out.  tbd: the block's time
     projection when the caller already computed it (decoder_forward batches the four blocks' projections)"""
     group = blk.norm_kind == "group"
@@ -1048,7 +1166,7 @@ def decoder_block_forward(blk, cur, skip, t, tbd=None):
     c2 = ConvFn.apply(a, blk.conv.weight, blk.conv.bias, None, None, 1, 1)
     if tbd is None and t is not None:
         tbd = _tproj(t, None, None, blk.sinusoidal_embedding, blk.time_projection_layer)
-    out = GroupNormFn.apply(c2, *g(blk.norm2), skip, tbd, act, G2, 1e-5)
+    out = GroupNormFn.apply(c2, *g(blk.norm2), skip, tbd, act, G2, 1e-5, sslot)
     if blk.compute_attn:
         out = _attention(blk.attention, out)
     return out
@@ -1081,7 +1199,7 @@ class _BucketBoundary(torch.autograd.Function):
         return dy, None, None
 
 
-def decoder_forward(dec, fmaps, t):
+def decoder_forward(dec, fmaps, t, skip_slots=None):
     """Decoder.forward up to (not including) final_layer.conv: the 4 residual blocks and the final block's upsampling convolution"""
     cur = fmaps[4]
     if _OVERLAP_BUCKET[0] is not None and torch.is_grad_enabled() and cur.requires_grad:
@@ -1093,7 +1211,7 @@ def decoder_forward(dec, fmaps, t):
         tbs = TimeProjMultiFn.apply(t, None, None, tuple(range(n)), n, *[b.sinusoidal_embedding.W for b in blocks],
                                     *[b.time_projection_layer[1].weight for b in blocks], *[b.time_projection_layer[1].bias for b in blocks])
     for i, blk in enumerate(blocks):
-        cur = decoder_block_forward(blk, cur, fmaps[3 - i], t, tbs[i])
+        cur = decoder_block_forward(blk, cur, fmaps[3 - i], t, tbs[i], skip_slots[3 - i] if skip_slots else None)
     return _upsampled(dec.final_layer, cur)
 
 
