@@ -149,7 +149,7 @@ def _pgrad(arena, like, zeroed):
 
 
 # Test instrumentation: when a list, every BatchNorm(+ReLU) forward appends the ReLU decision its backward will use
-# (relu output > 0, [B, H, W, C] bool).  tests/test_gpu_configs.py evaluates the float64 oracle under the SAME decisions: a
+# (relu output > 0, [B, H, W, C] bool).  tests/test_gpu_configs.py evaluates its float64 reference under the SAME decisions: a
 # pre-activation within rounding distance of zero otherwise routes its gradient differently in two arithmetics, and one such flip
 # moves an encoder weight gradient by ~1e-2.
 _RELU_TRACE = [None]
