@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round profile collection on the GPU box (run through gpurun from the repo root):
-#   bash tools/collect_profiles.sh r02
+#   bash tools/collect_profiles.sh r03
 # Per workload (C2 = BASELINE configs[1]: 128x128, batch 32, Euler-Maruyama;  C4 = configs[3]: 256x256, batch 16, predictor-corrector):
 # 1. bench.py autotune -> tile table saved
 # 2. rocprofv3 --kernel-trace --stats of the same command (same tile table)          -> <tag>_<wl>_kernel_stats.csv, _step_breakdown.txt
@@ -9,7 +9,7 @@
 # then the C3 training step (kernel trace -> <tag>_train_step_breakdown.txt, bench line).
 # Everything lands in gpurun_out/profiles_<tag>/ ; copy what should be judged into profiles/.
 set -eo pipefail
-TAG=${1:-r02}
+TAG=${1:-r03}
 OUT=gpurun_out/profiles_$TAG
 mkdir -p $OUT
 ROOT=$PWD
