@@ -575,7 +575,8 @@ int sbgm_model::attention(const AttnW& a, float* x, int B, int S, hipStream_t st
     // residual + LN2 + FF + residual).  Deep levels (few tokens, 256-512 channels) are bound by streaming 1-6 MB of weights: there
     // the separate GEMMs, which split the OUTPUT CHANNELS over the chip, stay faster (measured: 512 tokens x 512 channels 90 us
     // per fused kernel on 32 workgroups vs ~8 us per GEMM).
-    if (!no_fused && sbgm_attn_tokens_supported(C) && M >= 256 * 16) {
+    static const int fused_min_m = getenv("SBGM_ATTN_FUSED_MIN_M") ? atoi(getenv("SBGM_ATTN_FUSED_MIN_M")) : 256 * 16;
+    if (!no_fused && sbgm_attn_tokens_supported(C) && M >= fused_min_m) {
         float* qkv = wsalloc((size_t)M * 3 * C);
         if (!qkv) return 1;
         float* att = wsalloc((size_t)M * C);
