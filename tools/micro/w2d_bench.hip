@@ -43,12 +43,19 @@ int main(int argc, char** argv) {
     p.x = dx; p.wp = dwp; p.out = dout; p.bias = dbias; p.B = B; p.H = H; p.W = W; p.Cs = Cin; p.Cout = Cout; p.in_mode = in_mode;
 #ifdef EXP_STAMP
     unsigned long long* dstamp;
-    const size_t nstamp = (size_t)(W / 16) * ((H + 15) / 16) * B * (Cout / (16 * fco)) * 4 * 8;
+    const size_t nstamp = (size_t)(W / 16) * ((H + 15) / 16) * B * (Cout / (16 * (fco == 9 ? 2 : fco))) * 4 * 8;
     CK(hipMalloc(&dstamp, nstamp * 8)); CK(hipMemset(dstamp, 0, nstamp * 8));
     p.proj_out = reinterpret_cast<float*>(dstamp);
 #endif
-    ConvTile ct{fco, 1, 1, minw, 2, db ? 2 : 1};
-    if (sbgm_launch_conv_w2d(p, ct, nullptr)) return 1;
+    // db: 0 single buffer, 1 double buffer, 3 persistent kernel (minw = workgroups per CU).  fco 9 (with -DEXP_W2X and KFILE w2x.hip):
+    // the experimental 32x32x2 tiling
+    ConvTile ct{fco, 1, 1, minw, 2, db == 3 ? 3 : (db ? 2 : 1)};
+#ifdef EXP_W2X
+    auto launch = [&]() { return fco == 9 ? (db == 3 ? launch_w2xp(p, minw, nullptr) : launch_w2x(p, minw, db, nullptr)) : sbgm_launch_conv_w2d(p, ct, nullptr); };
+#else
+    auto launch = [&]() { return sbgm_launch_conv_w2d(p, ct, nullptr); };
+#endif
+    if (launch()) return 1;
     CK(hipDeviceSynchronize());
     // spot check against a direct fp64 convolution (in_mode 0 and 2-without-pre only)
     std::vector<float> ho((size_t)B * H * W * Cout);
@@ -79,7 +86,7 @@ int main(int argc, char** argv) {
     float best = 1e30f, tot = 0.f;
     for (int round = 0; round < 3; ++round) {
         CK(hipEventRecord(e0, nullptr));
-        for (int r = 0; r < reps; ++r) if (sbgm_launch_conv_w2d(p, ct, nullptr)) return 1;
+        for (int r = 0; r < reps; ++r) if (launch()) return 1;
         CK(hipEventRecord(e1, nullptr));
         CK(hipEventSynchronize(e1));
         float ms; CK(hipEventElapsedTime(&ms, e0, e1));
