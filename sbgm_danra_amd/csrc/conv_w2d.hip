@@ -748,28 +748,57 @@ __global__ __launch_bounds__(256, 2) void conv3x3_w2dp_kernel(const ConvParams p
                     }
                 }
                 if (PROJ) {
+                    // d[tap][px] = sum over this tile's NCO channels of w[tap][co] * y[px][co]: a lane holds 4 FCO of them, the 4 kq lanes
+                    // of a block the rest.  Reduce-SCATTER over kq (xor 32, then xor 16: 18 + 9 shuffles instead of 72 for an all-reduce):
+                    // lane kq ends up with taps kq and kq + 4 (4 pixels each) and pixel kq of tap 8, and stores them with 4 two-pixel
+                    // stores + 1 (a store instruction costs the wave 100+ cycles of issue; the all-reduce form needed 36)
                     const float* wlp = p.proj_w + co0 + 4 * kq;
-                    float* po = p.proj_out + (size_t)ct.co_tile * 9 * p.M;
+                    float s[9][4];
 #pragma unroll
                     for (int tap = 0; tap < 9; ++tap) {
-                        float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int px = 0; px < 4; ++px) s[tap][px] = 0.f;
 #pragma unroll
                         for (int i = 0; i < FCO; ++i) {
                             const f32x4 w4 = *reinterpret_cast<const f32x4*>(wlp + tap * p.Cout + 16 * i);
 #pragma unroll
                             for (int px = 0; px < 4; ++px)
 #pragma unroll
-                                for (int e = 0; e < 4; ++e) s[px] = fmaf(y[px][i][e], w4[e], s[px]);
+                                for (int e = 0; e < 4; ++e) s[tap][px] = fmaf(y[px][i][e], w4[e], s[tap][px]);
                         }
+                    }
+                    const bool hi = (kq & 2) != 0, odd = (kq & 1) != 0;
+                    float h[2][2][4], h8[2];                   // after xor 32: taps {0,1,4,5} (hi: {2,3,6,7}) as [t >> 2][t & 1][px]; tap 8 px {0,1} (hi: {2,3})
 #pragma unroll
-                        for (int px = 0; px < 4; ++px) {
-                            s[px] += __shfl_xor(s[px], 16, 64);
-                            s[px] += __shfl_xor(s[px], 32, 64);
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int c = 0; c < 2; ++c)
+#pragma unroll
+                            for (int px = 0; px < 4; ++px) {
+                                const float lo_v = s[4 * a + c][px], hi_v = s[4 * a + c + 2][px];
+                                h[a][c][px] = (hi ? hi_v : lo_v) + __shfl_xor(hi ? lo_v : hi_v, 32, 64);
+                            }
+#pragma unroll
+                    for (int c = 0; c < 2; ++c) {
+                        const float lo_v = s[8][c], hi_v = s[8][c + 2];
+                        h8[c] = (hi ? hi_v : lo_v) + __shfl_xor(hi ? lo_v : hi_v, 32, 64);
+                    }
+                    float f[2][4], f8;                          // after xor 16: taps kq, kq + 4; tap 8 pixel kq
+#pragma unroll
+                    for (int a = 0; a < 2; ++a)
+#pragma unroll
+                        for (int px = 0; px < 4; ++px) f[a][px] = (odd ? h[a][1][px] : h[a][0][px]) + __shfl_xor(odd ? h[a][0][px] : h[a][1][px], 16, 64);
+                    f8 = (odd ? h8[1] : h8[0]) + __shfl_xor(odd ? h8[0] : h8[1], 16, 64);
+                    if (ok) {
+                        float* po = p.proj_out + (size_t)ct.co_tile * 9 * p.M + m00;
+                        typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+                        for (int a = 0; a < 2; ++a) {
+                            float* o = po + (size_t)(4 * a + kq) * p.M;                 // m00, M and W are even: 8-byte aligned
+                            *reinterpret_cast<f32x2*>(o) = f32x2{f[a][0], f[a][1]};
+                            *reinterpret_cast<f32x2*>(o + p.W) = f32x2{f[a][2], f[a][3]};
                         }
-                        if (ok && kq == (tap & 3)) {
-                            float* o = po + (size_t)tap * p.M + m00;
-                            o[0] = s[0]; o[1] = s[1]; o[p.W] = s[2]; o[p.W + 1] = s[3];
-                        }
+                        po[(size_t)8 * p.M + (kq & 1) + (kq >> 1) * p.W] = f8;
                     }
                 }
                 if (want_stats) {

@@ -41,6 +41,26 @@ int main(int argc, char** argv) {
     if (sbgm_launch_pack_w2d_weight(dw, dwp, Cout, Cin, Cin, nullptr)) return 1;
     ConvParams p{};
     p.x = dx; p.wp = dwp; p.out = dout; p.bias = dbias; p.B = B; p.H = H; p.W = W; p.Cs = Cin; p.Cout = Cout; p.in_mode = in_mode;
+    // optional epilogue modes (environment): W2D_PROJ=1 -> tap projection of the final block (partial planes per co tile), W2D_STATS=G ->
+    // GroupNorm statistics with G groups; a checksum of what they wrote is printed so two builds can be compared
+    const bool want_proj = getenv("W2D_PROJ") != nullptr;
+    const int want_stats = getenv("W2D_STATS") ? atoi(getenv("W2D_STATS")) : 0;
+    float *dprojw = nullptr, *dproj = nullptr;
+    double* dstats = nullptr;
+    const size_t M = (size_t)B * H * W;
+    const int parts = Cout / (16 * (fco == 9 ? 2 : fco));
+    if (want_proj) {
+        std::vector<float> hpw((size_t)9 * Cout);
+        for (auto& v : hpw) v = nd(rng) * 0.1f;
+        CK(hipMalloc(&dprojw, hpw.size() * 4)); CK(hipMemcpy(dprojw, hpw.data(), hpw.size() * 4, hipMemcpyHostToDevice));
+        CK(hipMalloc(&dproj, (size_t)parts * 9 * M * 4)); CK(hipMemset(dproj, 0, (size_t)parts * 9 * M * 4));
+        p.proj_w = dprojw; p.proj_out = dproj;
+    }
+    const size_t nstat = (size_t)B * 64 * (want_stats ? want_stats : 1) * 2;
+    if (want_stats) {
+        CK(hipMalloc(&dstats, nstat * 8)); CK(hipMemset(dstats, 0, nstat * 8));
+        p.gn_stats = dstats; p.gn_groups = want_stats;
+    }
 #ifdef EXP_STAMP
     unsigned long long* dstamp;
     const size_t nstamp = (size_t)(W / 16) * ((H + 15) / 16) * B * (Cout / (16 * (fco == 9 ? 2 : fco))) * 4 * 8;
@@ -116,6 +136,25 @@ int main(int argc, char** argv) {
                a[3] / nw / st, a[4] / nw / st);
     }
 #endif
+    if (want_proj) {
+        std::vector<float> hp((size_t)parts * 9 * M);
+        CK(hipMemcpy(hp.data(), dproj, hp.size() * 4, hipMemcpyDeviceToHost));
+        double a = 0, b2 = 0;
+        for (size_t i = 0; i < hp.size(); ++i) { a += hp[i] * (double)((i % 251) + 1); b2 += fabs(hp[i]); }
+        printf("  proj checksum %.10e  abs %.10e\n", a, b2);
+    }
+    if (want_stats) {
+        std::vector<double> hs(nstat);
+        CK(hipMemcpy(hs.data(), dstats, nstat * 8, hipMemcpyDeviceToHost));
+        double a = 0, b2 = 0;
+        for (size_t i = 0; i < hs.size(); ++i) { a += hs[i] * (double)((i % 251) + 1); b2 += fabs(hs[i]); }
+        printf("  stats checksum %.14e  abs %.14e\n", a, b2);
+    }
+    {
+        double a = 0;
+        for (size_t i = 0; i < ho.size(); i += 7) a += ho[i] * (double)((i % 251) + 1);
+        if (!want_proj) printf("  out checksum %.10e\n", a);
+    }
     const double fl = 2.0 * B * H * W * (double)Cin * Cout * 9;
     printf("%d %dx%d %d->%d fco=%d minw=%d db=%d in=%d : %8.1f us (mean %8.1f)  %6.1f TF direct-equiv  %5.1f TF mfma   spot-err %.2e (ref max %.2f)\n", B, H, W, Cin, Cout, fco,
            minw, db, in_mode, best * 1e3, tot / 3 * 1e3, fl / best * 1e-9, fl * 4 / 9 / best * 1e-9, maxerr, maxref);
