@@ -593,7 +593,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # warm-up (untimed): graph capture / instantiate paths, caches, clocks
+    # warm-up (untimed): graph capture / instantiate paths, caches, clocks; the finite-check below loads its torch kernels here, not
+    # between two timed loops
+    assert torch.isfinite(cond).all()
     sampler(net, S.marginal_prob_std_fn, S.diffusion_coeff_fn, num_steps=max(2, a.warmup), **kw)
     barrier()
     t0 = time.perf_counter()

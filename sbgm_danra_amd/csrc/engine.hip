@@ -171,6 +171,8 @@ struct sbgm_model {
 
     int build(const sbgm_model_config& c);
     int ensure_ws(size_t bytes);
+    int dummy_forward(int B, int H, int W, bool tune, hipStream_t st);
+    int prepare_ws(int B, int H, int W, int bn_train, size_t factor, hipStream_t st);
     float* wsalloc(size_t floats) {     // bump allocator over the activation workspace; nullptr (+ error text) when full
         const size_t bytes = align_up(floats * 4, 256);
         if (ws_used + bytes > ws_bytes) {
@@ -1140,31 +1142,53 @@ int sbgm_model_forward(sbgm_model* m, const float* x, const float* t, const int6
 
 int sbgm_sampler_run(sbgm_model* m, const sbgm_sampler_args* a, void* stream) {
     SBGM_CHECK(a, "sampler_run: null args");
-    if (m->ensure_ws(m->ws_need(a->cfg_enabled ? 2 * a->B : a->B, a->H, a->W, a->bn_train))) return 1;
+    if (m->prepare_ws(a->cfg_enabled ? 2 * a->B : a->B, a->H, a->W, a->bn_train, 1, (hipStream_t)stream)) return 1;
     return m->sampler(*a, (hipStream_t)stream);
+}
+
+// One evaluation of the (B, H, W) plan on zero inputs placed at the top of the workspace.  tune = true: every convolution times its tile
+// candidates; tune = false: a plain evaluation whose only purpose is the bump allocator's high-water mark (ws_peak).
+int sbgm_model::dummy_forward(int B, int H, int W, bool tune, hipStream_t st) {
+    const size_t px = (size_t)B * H * W;
+    const size_t in_floats = px * 16 + 1024;
+    float* inp = reinterpret_cast<float*>(ws + ws_bytes - align_up(in_floats * 4, 256));
+    SBGM_HIP(hipMemsetAsync(inp, 0, in_floats * 4, st));
+    float* x = inp; float* t = inp + px; float* cond = t + 1024; float* lsm = cond + px * 8; float* topo = lsm + px * 2;
+    float* out = topo + px * 2;
+    if (sbgm_launch_fill_t(t, 0.5f, B, st)) return 1;
+    const size_t saved = ws_bytes;
+    ws_bytes -= align_up(in_floats * 4, 256);
+    tuning = tune;
+    ws_used = 0;
+    const int rc = forward(x, t, nullptr, cfg.n_cond_channels ? cond : nullptr, cfg.n_lsm_channels ? lsm : nullptr,
+                           cfg.n_topo_channels ? topo : nullptr, out, nullptr, B, H, W, 0, st);
+    tuning = false;
+    ws_bytes = saved;
+    SBGM_HIP(hipStreamSynchronize(st));
+    return rc;
+}
+
+// Workspace for an eval-mode call of this shape.  A shape seen for the first time is measured by one extra evaluation on zero inputs
+// BEFORE the caller's work, so the slab has its final size (and address) from the first real call on: a sampler's captured step graph
+// is then captured once, not again after a later call has trimmed the slab.  Train-mode BatchNorm shapes are not pre-measured (an
+// evaluation would move the running statistics): they run on the generous bound first and are trimmed by a later call.
+int sbgm_model::prepare_ws(int B, int H, int W, int bn_train, size_t factor, hipStream_t st) {
+    if (!bn_train && ws_peak.find(std::array<int, 4>{B, H, W, 0}) == ws_peak.end() && sbgm_model_check_complete(this) == 0) {
+        if (ensure_ws(ws_need(B, H, W) + ((size_t)B * H * W * 16 + 1024) * 4 + 4096)) return 1;
+        if (bn_dirty && fold_bn(st)) return 1;
+        if (dummy_forward(B, H, W, false, st)) return 1;
+    }
+    return ensure_ws(factor * ws_need(B, H, W, bn_train));
 }
 
 int sbgm_model_autotune(sbgm_model* m, int B, int H, int W, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (m->ensure_ws(2 * m->ws_need(B, H, W))) return 1;
-    // dummy inputs: zero-filled slabs at the top of the workspace
-    const size_t px = (size_t)B * H * W;
-    const size_t in_floats = px * 16 + 1024;
-    float* inp = reinterpret_cast<float*>(m->ws + m->ws_bytes - align_up(in_floats * 4, 256));
-    SBGM_HIP(hipMemsetAsync(inp, 0, in_floats * 4, st));
-    float* x = inp; float* t = inp + px; float* cond = t + 1024; float* lsm = cond + px * 8; float* topo = lsm + px * 2;
-    float* out = topo + px * 2;
-    if (sbgm_launch_fill_t(t, 0.5f, B, st)) return 1;
-    const size_t saved = m->ws_bytes;
-    m->ws_bytes -= align_up(in_floats * 4, 256);
-    m->tuning = true;
-    m->ws_used = 0;
-    const int rc = m->forward(x, t, nullptr, m->cfg.n_cond_channels ? cond : nullptr, m->cfg.n_lsm_channels ? lsm : nullptr,
-                              m->cfg.n_topo_channels ? topo : nullptr, out, nullptr, B, H, W, 0, st);
-    m->tuning = false;
-    m->ws_bytes = saved;
-    SBGM_HIP(hipStreamSynchronize(st));
-    return rc;
+    if (m->bn_dirty && m->fold_bn(st)) return 1;
+    if (m->dummy_forward(B, H, W, true, st)) return 1;
+    // the tuned plan's high-water mark, then the slab at its final size: what runs next (a sampler capturing its step) finds both settled
+    if (m->dummy_forward(B, H, W, false, st)) return 1;
+    return m->ensure_ws(m->ws_need(B, H, W));
 }
 
 extern "C++" {
