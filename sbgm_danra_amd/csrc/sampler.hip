@@ -75,9 +75,12 @@ __global__ void advance_kernel(SamplerState* state, const StepScalars* table, fl
     }
 }
 
-// per-sample sum of squares of the score, fp64 atomics into sumsq[B] (zeroed by the launcher)
+// per-sample sum of squares of the score, fp64 atomics into sumsq[B] (zeroed by the launcher): ONE atomic per workgroup (the four
+// wave sums meet in LDS first) and at most 16 workgroups per sample — same-address fp64 atomics retire at ~10 ns each, and one per wave
+// of a 64 x B grid made this 4 MB reduction a 41 us kernel at B = 16, 256 x 256
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ score, double* __restrict__ sumsq,
                                                     size_t per_sample4) {
+    __shared__ double part[4];
     const int b = blockIdx.y;
     const f32x4* s = reinterpret_cast<const f32x4*>(score) + (size_t)b * per_sample4;
     float acc = 0.f;
@@ -86,7 +89,9 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* __restrict__ sc
         acc += (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
     }
     const double w = wave_sum_d((double)acc);
-    if ((threadIdx.x & 63) == 0) atomicAdd(&sumsq[b], w);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(&sumsq[b], (part[0] + part[1]) + (part[2] + part[3]));
 }
 
 // Langevin corrector: eps = 2 (snr*sqrt(CHW) / mean_b ||score_b||)^2 ;  x += eps*score + sqrt(2 eps) N(0,1)
@@ -179,7 +184,7 @@ int sbgm_launch_langevin(float* x, const float* score, const float* z, float snr
                          size_t per_sample, hipStream_t st, NoiseMap nm) {
     SBGM_CHECK(per_sample % 4 == 0, "langevin: per-sample element count must be a multiple of 4");
     { if (sbgm_zero_async(sumsq_ws, sizeof(double) * B, st)) return 1; }
-    const int bx = (int)std::min<size_t>((per_sample / 4 + 255) / 256, 64);
+    const int bx = (int)std::min<size_t>((per_sample / 4 + 255) / 256, B >= 64 ? 4 : 16);
     hipLaunchKernelGGL(sumsq_kernel, dim3(bx, B), dim3(256), 0, st, score, sumsq_ws, per_sample / 4);
     SBGM_LAUNCH_CHECK();
     const size_t n4 = (size_t)B * per_sample / 4;
