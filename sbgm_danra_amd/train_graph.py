@@ -1278,18 +1278,40 @@ def decoder_block_call(blk, fmap, prev_fmap=None, t=None):
         assert tuple(prev_fmap.shape) == want, f"prev_fmap shape {tuple(prev_fmap.shape)} must match output shape {want}"   # reference :596-597
     else:
         prev_fmap = None
-    if t is not None and t.dim() > 1 and t.shape[-1] == blk.time_embedding:
-        raise NotImplementedError("DecoderBlock.forward takes the time vector [B]; a precomputed embedding is not supported natively")
+    # the reference accepts raw timesteps [B] or a PRECOMPUTED embedding [B, time_dim] (score_unet.py:604-609): the latter skips the
+    # block's SinusoidalEmbedding and goes straight through time_projection_layer = SiLU -> Linear
+    t_emb = None
+    if t is not None and t.dim() == 2 and t.shape[-1] == blk.time_embedding:
+        t_emb, t = N.f32c(t.to(fmap.device)), None
     tt = None if t is None else N.f32c(t.to(fmap.device).view(-1))
 
     def run():
         cur, skip = _ToNHWC.apply(N.f32c(fmap)), (None if prev_fmap is None else _ToNHWC.apply(N.f32c(prev_fmap)))
-        if isinstance(blk.norm1, torch.nn.Identity):        # the Decoder's final block: no norms, identity activation (:726-730)
+        tbd = None
+        if t_emb is not None:
+            lin = blk.time_projection_layer[1]
+            tbd = linear(ActFn.apply(t_emb, N.SILU), lin.weight, lin.bias)
+        if isinstance(blk.norm1, torch.nn.Identity) and isinstance(blk.norm2, torch.nn.Identity):
             a = _upsampled(blk, cur)
-            if blk.output_channels != 1 or skip is not None or tt is not None:
-                raise NotImplementedError("a norm-free DecoderBlock is implemented for the Decoder's final layer (C -> 1, no skip, no time)")
-            return Cout1Fn.apply(a, blk.conv.weight, blk.conv.bias, None, 0.0)              # already NCHW [B,1,H,W]
-        return _ToNCHW.apply(decoder_block_forward(blk, cur, skip, tt))
+            if blk.output_channels == 1 and skip is None and tt is None and tbd is None and isinstance(blk.activation, torch.nn.Identity):
+                # the Decoder's final block: no norms, no skip, no time, identity activation (:726-730)
+                return Cout1Fn.apply(a, blk.conv.weight, blk.conv.bias, None, 0.0)              # already NCHW [B,1,H,W]
+            # any other block whose norms were replaced by Identity (what Decoder does to its final layer, applied elsewhere):
+            # conv + skip + time projection ride on the convolution's epilogue, the activation and the attention follow
+            if blk.output_channels % 32:
+                raise NotImplementedError("a norm-free DecoderBlock needs output_channels % 32 == 0 (or the final layer's C -> 1 form)")
+            act = _ACT.get(type(blk.activation).__name__)
+            if act is None:
+                raise NotImplementedError(f"decoder activation {type(blk.activation).__name__} not implemented natively")
+            if tbd is None and tt is not None:
+                tbd = _tproj(tt, None, None, blk.sinusoidal_embedding, blk.time_projection_layer)
+            out = ConvFn.apply(a, blk.conv.weight, blk.conv.bias, skip, tbd, 1, 1)
+            if act != N.NONE:
+                out = ActFn.apply(out, act)
+            if blk.compute_attn:
+                out = _attention(blk.attention, out)
+            return _ToNCHW.apply(out)
+        return _ToNCHW.apply(decoder_block_forward(blk, cur, skip, tt, tbd))
     return _standalone(run)(fmap.device)
 
 

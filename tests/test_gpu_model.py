@@ -346,6 +346,18 @@ def test_standalone_submodule_calls_match_the_oracle(mode):
         bo = blk_o(fo[2], fo[1], t)
         bn = blk_n(fn[2], fn[1], t.cuda())
         assert maxrel(bn.detach().cpu(), bo.detach()) <= TOL
+        # a PRECOMPUTED time embedding [B, time_dim] instead of the time vector (reference :604-609): the block's own sinusoidal
+        # embedding is skipped, the value goes straight through SiLU -> Linear
+        emb = torch.randn(B, blk_o.time_embedding, generator=g)
+        emb_n = emb.cuda().requires_grad_(mode == "train")
+        bo2 = blk_o(fo[2], fo[1], emb)
+        bn2 = blk_n(fn[2], fn[1], emb_n)
+        assert maxrel(bn2.detach().cpu(), bo2.detach()) <= TOL
+        if mode == "train":                                  # ... and it is differentiable w.r.t. the embedding
+            emb_o = emb.clone().requires_grad_(True)
+            go, = torch.autograd.grad(blk_o(fo[2].detach(), fo[1].detach(), emb_o).square().mean(), emb_o)
+            gn, = torch.autograd.grad(blk_n(fn[2].detach(), fn[1].detach(), emb_n).square().mean(), emb_n)
+            assert maxrel(gn.cpu(), go) < 1e-4
         assert maxrel(net.decoder.final_layer(bn.new_zeros(B, 64, 32, 32) + 0.5).cpu(), ora.decoder.final_layer(torch.zeros(B, 64, 32, 32) + 0.5).detach()) <= TOL
     if mode == "train":
         do.square().mean().backward()
@@ -358,6 +370,22 @@ def test_standalone_submodule_calls_match_the_oracle(mode):
             assert maxrel(pn[k].grad.cpu(), po[k].grad) < tol, k
     with pytest.raises(AssertionError):                      # reference :596-597
         net.decoder.residual_layers[2](fn[2].detach(), fn[2].detach(), t.cuda())
+    # a block whose norms were replaced by Identity (what Decoder does to its final layer, :726-730) somewhere else: skip + time
+    # projection + activation (+ attention) without the norms
+    for i in (2, 1):                                         # block 1 has attention
+        bo_, bn_ = ora.decoder.residual_layers[i], net.decoder.residual_layers[i]
+        bo_.norm1 = bo_.norm2 = torch.nn.Identity()
+        bn_.norm1 = bn_.norm2 = torch.nn.Identity()
+        with ctx:
+            xo = fo[4 - i].detach().clone().requires_grad_(mode == "train")
+            xn = fn[4 - i].detach().clone().requires_grad_(mode == "train")
+            yo = bo_(xo, fo[3 - i].detach(), t)
+            yn = bn_(xn, fn[3 - i].detach(), t.cuda())
+            assert maxrel(yn.detach().cpu(), yo.detach()) <= TOL, i
+            if mode == "train":
+                go, = torch.autograd.grad(yo.square().mean(), xo)
+                gn, = torch.autograd.grad(yn.square().mean(), xn)
+                assert maxrel(gn.cpu(), go) < 1e-4, i
 
 
 def test_cached_step_graph_is_reused_across_runs_with_other_seeds_and_lengths():
