@@ -1045,6 +1045,8 @@ def _bn_eval(x, bn, res, tb_after, relu, rslot=None):
 
 def _attention(mod, x):                               # x: [B, H, W, C] -> same (reference score_unet.py:136-148)
     B, H, W, Cc = x.shape
+    if getattr(mod, "dropout", 0.0) > 0 and mod.training:
+        raise NotImplementedError("train-mode attention dropout (p > 0) is not implemented natively")
     tok = x.reshape(B * H * W, Cc)
     grad = torch.is_grad_enabled() and tok.requires_grad
     s1 = _slot(2) if grad else None                          # tok feeds ln1 and the residual of out_proj

@@ -413,3 +413,14 @@ def test_graft_entry_build_hook():
     """The driver's build hook and the first command of INTEGRATION.md: make (a no-op when current) + dlopen + ABI check."""
     import __graft_entry__ as G
     G.build()
+
+
+def test_attention_dropout_is_accepted_like_the_reference_signature():
+    """ImageSelfAttention(..., dropout=p) (reference score_unet.py:118-127) constructs with p > 0 — the identity in eval mode, which the
+    sampling path uses; only a train-mode evaluation with p > 0 is refused (at call time)"""
+    import sbgm_danra_amd as S
+    a = S.ImageSelfAttention(64, 4, dropout=0.1)
+    assert a.dropout == 0.1 and a.mha.dropout == 0.1
+    assert set(a.state_dict()) == set(S.ImageSelfAttention(64, 4).state_dict())
+    with pytest.raises(ValueError):
+        S.ImageSelfAttention(30, 4)
