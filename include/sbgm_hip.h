@@ -241,7 +241,10 @@ int sbgm_set_scratch_prezeroed(int on);
  * and converts it to OIHW with a small layout launch.  With sbgm_wgrad_defer(1) in force that launch is queued instead, and
  * sbgm_wgrad_flush runs every queued conversion as ONE launch (21 per training step of the default model): the caller keeps the
  * queued ws / dw_oihw buffers alive and untouched until the flush, after which dw_oihw holds the gradients.  Process-wide, returns
- * the previous value; sbgm_wgrad_flush_pending() = number of queued conversions. */
+ * the previous value; sbgm_wgrad_flush_pending() = number of queued conversions.
+ * `on` is a bit mask: bit 0 = the layout passes as above; bit 1 (2) = also queue the weight-gradient GEMMs of the layers the per-tap
+ * split-K kernel serves (1x1 / linear, 3x3 stride 2, 3x3 on 4x4 maps, the 8x8 stems) and run them as ONE batched launch at the flush —
+ * the caller then keeps dy, x, ws and dw_oihw (and dbias) of every call made under the flag alive and untouched until the flush. */
 int sbgm_wgrad_defer(int on);
 int sbgm_wgrad_flush(void* stream);
 int sbgm_wgrad_flush_pending(void);

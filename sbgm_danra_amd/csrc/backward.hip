@@ -314,10 +314,24 @@ constexpr int W1_PX = 128, W1_PS = 80;             // pixels per tile, LDS float
 struct TapGeom {
     int Mo, OH, OW, H, W, stride, pad, KW, taps, stem;
 };
-__global__ __launch_bounds__(WG_THREADS) void conv_tap_wgrad_lds_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                                        float* __restrict__ dwp, float* __restrict__ dbias, TapGeom g,
-                                                                        int Cs, int Cout, int tiles_per_wg, uint32_t dy_bytes,
-                                                                        uint32_t x_bytes, float* __restrict__ dw_direct, int Cin) {
+// one launch's arguments; the batched form (every small weight gradient of a backward sweep in ONE launch, below) carries an array of them
+struct TapDesc {
+    const float *dy, *x;
+    float *dwp, *dbias, *dw_direct;
+    TapGeom g;
+    int Cs, Cout, tiles_per_wg, Cin, gx, gy;
+    uint32_t dy_bytes, x_bytes;
+};
+
+__device__ __forceinline__ void tap_wgrad_body(const TapDesc& a, const int bx, const int by) {
+    const float* __restrict__ dy = a.dy;
+    const float* __restrict__ x = a.x;
+    float* __restrict__ dwp = a.dwp;
+    float* __restrict__ dbias = a.dbias;
+    float* __restrict__ dw_direct = a.dw_direct;
+    const TapGeom g = a.g;
+    const int Cs = a.Cs, Cout = a.Cout, tiles_per_wg = a.tiles_per_wg, Cin = a.Cin;
+    const uint32_t dy_bytes = a.dy_bytes, x_bytes = a.x_bytes;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* dys = reinterpret_cast<float*>(smem_raw);                   // [128 px][80]
     float* xs = dys + W1_PX * W1_PS;                                   // [128 px][80]
@@ -325,7 +339,7 @@ __global__ __launch_bounds__(WG_THREADS) void conv_tap_wgrad_lds_kernel(const fl
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, kq = lane >> 4;
     const int n_ci = g.stem ? 1 : Cs / 64, n_co = Cout / 64;
-    int blk = blockIdx.x;
+    int blk = bx;
     const int ci0 = (blk % n_ci) * 64; blk /= n_ci;
     const int co0 = (blk % n_co) * 64;
     const int tap = blk / n_co;
@@ -333,7 +347,7 @@ __global__ __launch_bounds__(WG_THREADS) void conv_tap_wgrad_lds_kernel(const fl
     const int slab_cs = g.stem ? 64 : Cs;                              // floats per (tap, co) row of the slab
     dwp += (size_t)tap * Cout * slab_cs;
     const int n_tiles = (g.Mo + W1_PX - 1) / W1_PX;
-    const int t_begin = blockIdx.y * tiles_per_wg, t_end = min(n_tiles, t_begin + tiles_per_wg);
+    const int t_begin = by * tiles_per_wg, t_end = min(n_tiles, t_begin + tiles_per_wg);
     const __amdgpu_buffer_rsrc_t dr = make_rsrc(dy, dy_bytes);
     const __amdgpu_buffer_rsrc_t xr = make_rsrc(x, x_bytes);
     const bool shifted = g.stride != 1 || g.taps != 1 || g.pad != 0;
@@ -436,6 +450,27 @@ __global__ __launch_bounds__(WG_THREADS) void conv_tap_wgrad_lds_kernel(const fl
             else atomicAdd(dwp + (size_t)co * slab_cs + ci, o[e]);
         }
     }
+}
+
+__global__ __launch_bounds__(WG_THREADS) void conv_tap_wgrad_lds_kernel(const TapDesc a) { tap_wgrad_body(a, blockIdx.x, blockIdx.y); }
+
+// Batched form.  At training batch sizes a step has ~27 of these GEMMs (16 attention linears, the stride-2 and 1x1 shortcut convolutions,
+// the 3x3 layers on 4x4 maps, the two stems), 0.1-4 GFLOP each: launched one by one each fills the chip with ~256 workgroups that own a
+// tile or two and then pay the LDS fold and 4096 atomics, 13.8 us per launch on average.  Queued during the backward sweep and
+// launched together, the layers fill the chip between them, so every layer splits its pixels over far fewer workgroups.
+constexpr int TAP_MAX = 28;
+struct TapTable {
+    TapDesc d[TAP_MAX];
+    int start[TAP_MAX + 1];
+    int n;
+};
+__global__ __launch_bounds__(WG_THREADS) void conv_tap_wgrad_batched_kernel(const TapTable t) {
+    int k = 0;
+    while (k + 1 < t.n && (int)blockIdx.x >= t.start[k + 1]) ++k;
+    k = __builtin_amdgcn_readfirstlane(k);
+    const int rel = blockIdx.x - t.start[k];
+    const int gx = t.d[k].gx;
+    tap_wgrad_body(t.d[k], rel % gx, rel / gx);
 }
 
 // stem slab [kh][Cout][kw][8] -> OIHW [Cout][Cin][KH][8]
@@ -1145,11 +1180,15 @@ __global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ 
 // Deferred slab -> OIHW passes (sbgm_wgrad_defer / sbgm_wgrad_flush in the C ABI): while deferral is on, sbgm_launch_conv_wgrad
 // queues its layout pass instead of launching it; the flush at the end of the backward sweep runs all of them as one kernel.
 // The caller keeps every queued slab alive and untouched until the flush.  Process-wide, like the prezeroed switch.
+// sbgm_wgrad_deferred bit 0: queue the layout passes; bit 1: queue the per-tap split-K GEMMs themselves (conv_tap_wgrad_lds_kernel) and run
+// them as ONE batched launch at the flush — the caller then also keeps dy and x of every queued call alive until the flush.
 int sbgm_wgrad_deferred = 0;
 static std::vector<UnpackDesc> g_unpack_queue;
+struct TapQueued { TapDesc d; int n_tiles; float* dw_oihw; int unpack_taps; bool aliased; };     // unpack_taps: as UnpackDesc.taps
+static std::vector<TapQueued> g_tap_queue;
 
 static int unpack_or_queue(const float* src, float* dst, int Cout, int Cin, int Cs, int taps, hipStream_t st) {
-    if (sbgm_wgrad_deferred) {
+    if (sbgm_wgrad_deferred & 1) {
         g_unpack_queue.push_back(UnpackDesc{src, dst, Cout, Cin, Cs, taps});
         return 0;
     }
@@ -1160,11 +1199,66 @@ static int unpack_or_queue(const float* src, float* dst, int Cout, int Cin, int 
     return 0;
 }
 
-int sbgm_wgrad_pending() { return (int)g_unpack_queue.size(); }
-// forget the queued layout passes without running them (a backward pass that raised: their destination tensors may be gone)
-void sbgm_wgrad_discard_queue() { g_unpack_queue.clear(); }
+int sbgm_wgrad_pending() { return (int)(g_unpack_queue.size() + g_tap_queue.size()); }
+// forget the queued work without running it (a backward pass that raised: the tensors it points at may be gone)
+void sbgm_wgrad_discard_queue() { g_unpack_queue.clear(); g_tap_queue.clear(); }
+
+static int tap_set_attr() {
+    static bool done = false;
+    if (!done) {
+        const int lds = 2 * W1_PX * W1_PS * 4;
+        SBGM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tap_wgrad_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        SBGM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tap_wgrad_batched_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        done = true;
+    }
+    return 0;
+}
+
+// the queued per-tap GEMMs: split each layer's pixels so that all layers together make ~4 workgroups per CU, launch, queue the layout passes
+static int tap_flush(hipStream_t st) {
+    if (g_tap_queue.empty()) return 0;
+    if (tap_set_attr()) return 1;
+    static const int target = getenv("SBGM_TAP_BATCH_WGS") ? atoi(getenv("SBGM_TAP_BATCH_WGS")) : 1024;
+    double work = 0.0;
+    for (auto& q : g_tap_queue) work += (double)q.d.gx * q.n_tiles;
+    const size_t lds = (size_t)2 * W1_PX * W1_PS * 4;
+    size_t i = 0;
+    while (i < g_tap_queue.size()) {
+        TapTable t{};
+        int nb = 0;
+        for (; i < g_tap_queue.size() && t.n < TAP_MAX; ++i) {
+            TapQueued& q = g_tap_queue[i];
+            TapDesc d = q.d;
+            const double share = (double)d.gx * q.n_tiles / work;
+            int gy = (int)std::lround(target * share / d.gx);
+            gy = std::max(1, std::min(gy, q.n_tiles));
+            d.tiles_per_wg = (q.n_tiles + gy - 1) / gy;
+            d.gy = (q.n_tiles + d.tiles_per_wg - 1) / d.tiles_per_wg;
+            // no pixel split: plain OIHW stores, no slab, no layout pass (not for the stem's slab layout)
+            const bool direct = d.gy == 1 && !d.g.stem;
+            d.dw_direct = direct ? q.dw_oihw : nullptr;
+            if (q.d.g.stem) g_unpack_queue.push_back(UnpackDesc{d.dwp, q.dw_oihw, d.Cout, d.Cin, d.Cs, q.unpack_taps});
+            else if (!direct && !q.aliased) g_unpack_queue.push_back(UnpackDesc{d.dwp, q.dw_oihw, d.Cout, d.Cin, d.Cs, q.unpack_taps});
+            t.d[t.n] = d;
+            t.start[t.n] = nb;
+            nb += d.gx * d.gy;
+            ++t.n;
+        }
+        t.start[t.n] = nb;
+        hipLaunchKernelGGL(conv_tap_wgrad_batched_kernel, dim3(nb), dim3(WG_THREADS), lds, st, t);
+        if (hipGetLastError() != hipSuccess) {
+            g_tap_queue.clear();
+            g_unpack_queue.clear();
+            sbgm_set_error("wgrad_flush: batched weight-gradient launch failed");
+            return 1;
+        }
+    }
+    g_tap_queue.clear();
+    return 0;
+}
 
 int sbgm_launch_wgrad_flush(hipStream_t st) {
+    if (tap_flush(st)) return 1;
     size_t i = 0;
     const size_t n = g_unpack_queue.size();
     while (i < n) {
@@ -1243,21 +1337,23 @@ int sbgm_launch_conv_wgrad(const float* dy, const float* x, float* dw_oihw, floa
         const int tpw = (n_tiles + wgs_y - 1) / wgs_y;
         const dim3 grid_lds(blocks_x, (n_tiles + tpw - 1) / tpw);
         const size_t lds = (size_t)2 * W1_PX * W1_PS * 4;
-        static bool attr1_set = false;
-        if (!attr1_set) {
-            SBGM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv_tap_wgrad_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         (int)lds));
-            attr1_set = true;
-        }
-        float* direct = grid_lds.y == 1 && !stem ? dw_oihw : nullptr;
+        if (tap_set_attr()) return 1;
         // ws == dw_oihw: for a 1x1 kernel without channel padding the slab IS the OIHW gradient, so the caller may hand in the
         // (zeroed) gradient tensor as workspace and no unpack pass is needed
         const bool aliased = dwp_ws == dw_oihw;
         SBGM_CHECK(!aliased || (KH * KW == 1 && Cs == Cin), "wgrad: ws may alias dw only for 1x1 kernels with c_pad == Cin");
-        if (!direct && !sbgm_scratch_prezeroed) { if (sbgm_zero_async(dwp_ws, n * 4, st)) return 1; }
         const TapGeom tg{M, OH, OW, H, W, S, PAD, KW, KH * KW, stem ? 1 : 0};
-        hipLaunchKernelGGL(conv_tap_wgrad_lds_kernel, grid_lds, dim3(WG_THREADS), lds, st, dy, x, dwp_ws, dbias, tg, Cs, Cout, tpw,
-                           (uint32_t)dy_b, (uint32_t)x_b, direct, Cin);
+        TapDesc d{dy, x, dwp_ws, dbias, nullptr, tg, Cs, Cout, tpw, Cin, blocks_x, (int)grid_lds.y, (uint32_t)dy_b, (uint32_t)x_b};
+        if (sbgm_wgrad_deferred & 2) {
+            // queued: the slab may still be needed (the split is decided at the flush), so it is zeroed now unless it arrives zeroed
+            if (!sbgm_scratch_prezeroed) { if (sbgm_zero_async(dwp_ws, n * 4, st)) return 1; }
+            g_tap_queue.push_back(TapQueued{d, n_tiles, dw_oihw, stem ? -KH : KH * KW, aliased});
+            return 0;
+        }
+        float* direct = grid_lds.y == 1 && !stem ? dw_oihw : nullptr;
+        if (!direct && !sbgm_scratch_prezeroed) { if (sbgm_zero_async(dwp_ws, n * 4, st)) return 1; }
+        d.dw_direct = direct;
+        hipLaunchKernelGGL(conv_tap_wgrad_lds_kernel, grid_lds, dim3(WG_THREADS), lds, st, d);
         SBGM_LAUNCH_CHECK();
         if (stem) return unpack_or_queue(dwp_ws, dw_oihw, Cout, Cin, Cs, -KH, st);
         if (!direct && !aliased) return unpack_or_queue(dwp_ws, dw_oihw, Cout, Cin, Cs, KH * KW, st);

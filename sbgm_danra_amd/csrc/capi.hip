@@ -140,7 +140,7 @@ int sbgm_set_scratch_prezeroed(int on) {
 }
 int sbgm_wgrad_defer(int on) {
     const int prev = sbgm_wgrad_deferred;
-    sbgm_wgrad_deferred = on ? 1 : 0;
+    sbgm_wgrad_deferred = on & 3;
     return prev;
 }
 int sbgm_wgrad_flush(void* stream) { return sbgm_launch_wgrad_flush(ST); }

@@ -65,6 +65,7 @@ _ZERO = {}             # device -> [buffer, offset, high-water mark, usable exte
 def _zero_reset(dev):
     if _L().sbgm_wgrad_flush_pending():           # a backward pass that raised before its end-of-pass callback: its queued layout
         _L().sbgm_wgrad_discard()                 # passes point at gradient tensors that may be freed by now — drop them unrun
+    _DEFER_KEEP.clear()
     _FLUSH_QUEUED[0] = False
     z = _ZERO.get(dev)
     if z is None:
@@ -133,6 +134,16 @@ def arena_for(net, create=True):
         a = GradArena(net)
         object.__setattr__(net, "_grad_arena", a)
     return a
+
+
+_BATCH_WGRAD = [True]  # queue the small weight-gradient GEMMs of a backward sweep for one batched launch (sbgm_wgrad_defer bit 1)
+
+
+def _in_arena(arena, t):
+    if arena is None or t is None:
+        return False
+    a = arena.flat.data_ptr()
+    return a <= t.data_ptr() < a + arena.flat.numel() * 4
 
 
 def _pgrad(arena, like, zeroed):
@@ -280,19 +291,31 @@ _DEFER_UNPACK = [True]
 _FLUSH_QUEUED = [False]
 
 
+_DEFER_KEEP = []       # (dy, x) of the weight-gradient GEMMs queued for the batched launch: alive until the flush has enqueued them
+
+
 def _flush_wgrad():
     _FLUSH_QUEUED[0] = False
-    if _L().sbgm_wgrad_flush_pending():
-        N.check(_L().sbgm_wgrad_flush(_st()))
+    try:
+        if _L().sbgm_wgrad_flush_pending():
+            N.check(_L().sbgm_wgrad_flush(_st()))
+    finally:
+        _DEFER_KEEP.clear()
 
 
 class _deferred_unpack:
-    def __init__(self, on):
-        self.on = on and _DEFER_UNPACK[0]
+    """`on`: the slab -> OIHW pass of this call may wait for the end of the backward sweep; `gemm`: so may the weight-gradient GEMM itself
+    (sbgm_wgrad_defer bit 1: the small per-tap GEMMs of a sweep run as one batched launch) — `keep` = the tensors it reads, held until then"""
+    def __init__(self, on, gemm=False, keep=()):
+        self.mask = ((1 if on else 0) | (2 if gemm else 0)) if _DEFER_UNPACK[0] else 0
+        self.on = self.mask != 0
+        self.keep = keep if (self.mask & 2) else ()
 
     def __enter__(self):
         if self.on:
-            self.prev = _L().sbgm_wgrad_defer(1)
+            self.prev = _L().sbgm_wgrad_defer(self.mask)
+            if self.keep:
+                _DEFER_KEEP.append(self.keep)
 
     def __exit__(self, *exc):
         if self.on:
@@ -587,14 +610,16 @@ class ConvFn(torch.autograd.Function):
                 # the layout pass may run at the end of the backward sweep only when nothing consumes dw before that: an arena
                 # slice becomes p.grad as it is; a fresh tensor may be added to a live .grad by AccumulateGrad right away
                 defer = pooled and in_arena
+            # the GEMM itself may join the sweep's batched launch when its results land in the arena (nothing reads them before the flush)
+            gemm_defer = _BATCH_WGRAD[0] and pooled and _in_arena(arena, dw) and torch.is_grad_enabled() is False
             if want_db and pooled:                               # bias gradient as a by-product of the weight-gradient sweep
                 db, _ = _pgrad(arena, bias, True)                # a returned gradient: never a slice of the re-zeroed scratch pool
-                with _prezeroed(True), _deferred_unpack(ws is not dw and defer):
+                with _prezeroed(True), _deferred_unpack(ws is not dw and defer, gemm_defer and _in_arena(arena, db), (dy, x)):
                     N.check(_L().sbgm_conv2d_wgrad_bias(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), B, H, W,
                                                         cs, cin, cout, k, k, stride, pad, _st()))
                 want_db = False
             else:
-                with _prezeroed(pooled), _deferred_unpack(ws is not dw and defer):
+                with _prezeroed(pooled), _deferred_unpack(ws is not dw and defer, gemm_defer, (dy, x)):
                     N.check(_L().sbgm_conv2d_wgrad(dy.data_ptr(), x.data_ptr(), dw.data_ptr(), ws.data_ptr(), B, H, W, cs, cin, cout, k, k,
                                                    stride, pad, _st()))
         if want_db:
