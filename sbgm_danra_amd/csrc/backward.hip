@@ -138,12 +138,23 @@ constexpr int WG_DY_FLOATS = 256 * WG_PS;
 template <int TW> struct WgTile {
     static constexpr int PW = TW + 2, PH = TW == 16 ? 18 : 40, X_FLOATS = PH * PW * WG_PS;
 };
+// one launch's arguments; the batched form (every 3x3 weight gradient of a backward sweep in one launch per tile geometry) carries an array
+struct HaloDesc {
+    const float *dy, *x;
+    float *dwp, *dbias, *dw_direct;
+    int B, H, W, Cs, Cout, tiles_per_wg, Cin, gx, gy;
+    uint32_t dy_bytes, x_bytes;
+};
+
 template <int TW>
-__global__ __launch_bounds__(WG_THREADS) void conv3x3_wgrad_lds_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                                       float* __restrict__ dwp, float* __restrict__ dbias, int B,
-                                                                       int H, int W, int Cs, int Cout, int tiles_per_wg,
-                                                                       uint32_t dy_bytes, uint32_t x_bytes, float* __restrict__ dw_direct,
-                                                                       int Cin) {
+__device__ __forceinline__ void halo_wgrad_body(const HaloDesc& a, const int bx, const int by) {
+    const float* __restrict__ dy = a.dy;
+    const float* __restrict__ x = a.x;
+    float* __restrict__ dwp = a.dwp;
+    float* __restrict__ dbias = a.dbias;
+    float* __restrict__ dw_direct = a.dw_direct;
+    const int B = a.B, H = a.H, W = a.W, Cs = a.Cs, Cout = a.Cout, tiles_per_wg = a.tiles_per_wg, Cin = a.Cin;
+    const uint32_t dy_bytes = a.dy_bytes, x_bytes = a.x_bytes;
     constexpr int PW = WgTile<TW>::PW, PH = WgTile<TW>::PH;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     float* dys = reinterpret_cast<float*>(smem_raw);                   // [256 px][48]
@@ -152,10 +163,10 @@ __global__ __launch_bounds__(WG_THREADS) void conv3x3_wgrad_lds_kernel(const flo
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r16 = lane & 15, kq = lane >> 4;
     const int n_ci = Cs / 32;
-    const int co0 = (blockIdx.x / n_ci) * 32, ci0 = (blockIdx.x % n_ci) * 32;
+    const int co0 = (bx / n_ci) * 32, ci0 = (bx % n_ci) * 32;
     const int tiles_x = W / 16, tiles_img = tiles_x * (H / 16);        // TW = 16 only
     const int n_tiles = TW == 16 ? B * tiles_img : (B + 3) / 4;
-    const int t_begin = blockIdx.y * tiles_per_wg, t_end = min(n_tiles, t_begin + tiles_per_wg);
+    const int t_begin = by * tiles_per_wg, t_end = min(n_tiles, t_begin + tiles_per_wg);
     const __amdgpu_buffer_rsrc_t dr = make_rsrc(dy, dy_bytes);
     const __amdgpu_buffer_rsrc_t xr = make_rsrc(x, x_bytes);
 
@@ -297,6 +308,27 @@ __global__ __launch_bounds__(WG_THREADS) void conv3x3_wgrad_lds_kernel(const flo
                 }
         }
     }
+}
+
+template <int TW>
+__global__ __launch_bounds__(WG_THREADS) void conv3x3_wgrad_lds_kernel(const HaloDesc a) { halo_wgrad_body<TW>(a, blockIdx.x, blockIdx.y); }
+
+// Batched form (see the per-tap kernel's batched form below for the rationale): at batch 8 most of a step's 19 3x3 layers own 2-8 tiles
+// per workgroup before the 9-tap LDS fold and 36 KB of atomics; launched together they split their pixels over far fewer workgroups.
+constexpr int HALO_MAX = 30;
+struct HaloTable {
+    HaloDesc d[HALO_MAX];
+    int start[HALO_MAX + 1];
+    int n;
+};
+template <int TW>
+__global__ __launch_bounds__(WG_THREADS) void conv3x3_wgrad_batched_kernel(const HaloTable t) {
+    int k = 0;
+    while (k + 1 < t.n && (int)blockIdx.x >= t.start[k + 1]) ++k;
+    k = __builtin_amdgcn_readfirstlane(k);
+    const int rel = blockIdx.x - t.start[k];
+    const int gx = t.d[k].gx;
+    halo_wgrad_body<TW>(t.d[k], rel % gx, rel / gx);
 }
 
 // =====================================================================================================================
@@ -1186,6 +1218,8 @@ int sbgm_wgrad_deferred = 0;
 static std::vector<UnpackDesc> g_unpack_queue;
 struct TapQueued { TapDesc d; int n_tiles; float* dw_oihw; int unpack_taps; bool aliased; };     // unpack_taps: as UnpackDesc.taps
 static std::vector<TapQueued> g_tap_queue;
+struct HaloQueued { HaloDesc d; int n_tiles; float* dw_oihw; };
+static std::vector<HaloQueued> g_halo_queue[2];            // [0]: 16 x 16 tiles, [1]: 8 x 8 maps (4 images per tile)
 
 static int unpack_or_queue(const float* src, float* dst, int Cout, int Cin, int Cs, int taps, hipStream_t st) {
     if (sbgm_wgrad_deferred & 1) {
@@ -1199,9 +1233,9 @@ static int unpack_or_queue(const float* src, float* dst, int Cout, int Cin, int 
     return 0;
 }
 
-int sbgm_wgrad_pending() { return (int)(g_unpack_queue.size() + g_tap_queue.size()); }
+int sbgm_wgrad_pending() { return (int)(g_unpack_queue.size() + g_tap_queue.size() + g_halo_queue[0].size() + g_halo_queue[1].size()); }
 // forget the queued work without running it (a backward pass that raised: the tensors it points at may be gone)
-void sbgm_wgrad_discard_queue() { g_unpack_queue.clear(); g_tap_queue.clear(); }
+void sbgm_wgrad_discard_queue() { g_unpack_queue.clear(); g_tap_queue.clear(); g_halo_queue[0].clear(); g_halo_queue[1].clear(); }
 
 static int tap_set_attr() {
     static bool done = false;
@@ -1257,7 +1291,63 @@ static int tap_flush(hipStream_t st) {
     return 0;
 }
 
+static int halo_set_attr() {
+    static bool done = false;
+    if (!done) {
+        const int l16 = (WG_DY_FLOATS + WgTile<16>::X_FLOATS) * 4, l8 = (WG_DY_FLOATS + WgTile<8>::X_FLOATS) * 4;
+        SBGM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_lds_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, l16));
+        SBGM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_lds_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, l8));
+        SBGM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_batched_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, l16));
+        SBGM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_batched_kernel<8>), hipFuncAttributeMaxDynamicSharedMemorySize, l8));
+        done = true;
+    }
+    return 0;
+}
+
+// the queued 3x3 weight gradients of one tile geometry: pixels split by each layer's share of the total work (one 8-wave workgroup per CU
+// is resident: `target` workgroups = target / 256 rounds), one launch, layout passes queued behind it
+static int halo_flush(int which, hipStream_t st) {
+    std::vector<HaloQueued>& qv = g_halo_queue[which];
+    if (qv.empty()) return 0;
+    if (halo_set_attr()) return 1;
+    static const int target = getenv("SBGM_HALO_BATCH_WGS") ? atoi(getenv("SBGM_HALO_BATCH_WGS")) : 768;
+    double work = 0.0;
+    for (auto& q : qv) work += (double)q.d.gx * q.n_tiles;
+    const size_t lds = (size_t)(WG_DY_FLOATS + (which == 0 ? WgTile<16>::X_FLOATS : WgTile<8>::X_FLOATS)) * 4;
+    size_t i = 0;
+    while (i < qv.size()) {
+        HaloTable t{};
+        int nb = 0;
+        for (; i < qv.size() && t.n < HALO_MAX; ++i) {
+            HaloQueued& q = qv[i];
+            HaloDesc d = q.d;
+            int gy = (int)std::lround(target * ((double)d.gx * q.n_tiles / work) / d.gx);
+            gy = std::max(1, std::min(gy, q.n_tiles));
+            d.tiles_per_wg = (q.n_tiles + gy - 1) / gy;
+            d.gy = (q.n_tiles + d.tiles_per_wg - 1) / d.tiles_per_wg;
+            const bool direct = d.gy == 1;                   // no pixel split: plain OIHW stores, no slab, no layout pass
+            d.dw_direct = direct ? q.dw_oihw : nullptr;
+            if (!direct) g_unpack_queue.push_back(UnpackDesc{d.dwp, q.dw_oihw, d.Cout, d.Cin, d.Cs, 9});
+            t.d[t.n] = d;
+            t.start[t.n] = nb;
+            nb += d.gx * d.gy;
+            ++t.n;
+        }
+        t.start[t.n] = nb;
+        if (which == 0) hipLaunchKernelGGL(conv3x3_wgrad_batched_kernel<16>, dim3(nb), dim3(WG_THREADS), lds, st, t);
+        else hipLaunchKernelGGL(conv3x3_wgrad_batched_kernel<8>, dim3(nb), dim3(WG_THREADS), lds, st, t);
+        if (hipGetLastError() != hipSuccess) {
+            sbgm_wgrad_discard_queue();
+            sbgm_set_error("wgrad_flush: batched 3x3 weight-gradient launch failed");
+            return 1;
+        }
+    }
+    qv.clear();
+    return 0;
+}
+
 int sbgm_launch_wgrad_flush(hipStream_t st) {
+    if (halo_flush(0, st) || halo_flush(1, st)) return 1;
     if (tap_flush(st)) return 1;
     size_t i = 0;
     const size_t n = g_unpack_queue.size();
@@ -1307,22 +1397,18 @@ int sbgm_launch_conv_wgrad(const float* dy, const float* x, float* dw_oihw, floa
         const int wgs_y = std::max(1, std::min(n_tiles, (256 + blocks_x - 1) / blocks_x));      // one 8-wave workgroup per CU
         const int tpw = (n_tiles + wgs_y - 1) / wgs_y;
         const dim3 grid_lds(blocks_x, (n_tiles + tpw - 1) / tpw);
-        static bool attr_set = false;
-        if (!attr_set) {
-            SBGM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_lds_kernel<16>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (WG_DY_FLOATS + WgTile<16>::X_FLOATS) * 4));
-            SBGM_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(conv3x3_wgrad_lds_kernel<8>),
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (WG_DY_FLOATS + WgTile<8>::X_FLOATS) * 4));
-            attr_set = true;
+        if (halo_set_attr()) return 1;
+        HaloDesc d{dy, x, dwp_ws, dbias, nullptr, B, H, W, Cs, Cout, tpw, Cin, blocks_x, (int)grid_lds.y, (uint32_t)dy_b, (uint32_t)x_b};
+        if (sbgm_wgrad_deferred & 2) {                      // queued for the sweep's batched launch (the split is decided at the flush)
+            if (!sbgm_scratch_prezeroed) { if (sbgm_zero_async(dwp_ws, n * 4, st)) return 1; }
+            g_halo_queue[lds16 ? 0 : 1].push_back(HaloQueued{d, n_tiles, dw_oihw});
+            return 0;
         }
         float* direct = grid_lds.y == 1 ? dw_oihw : nullptr;          // no pixel split: no atomics, no slab, no unpack pass
         if (!direct && !sbgm_scratch_prezeroed) { if (sbgm_zero_async(dwp_ws, n * 4, st)) return 1; }
-        if (lds16)
-            hipLaunchKernelGGL(conv3x3_wgrad_lds_kernel<16>, grid_lds, dim3(WG_THREADS), (size_t)(WG_DY_FLOATS + WgTile<16>::X_FLOATS) * 4, st,
-                               dy, x, dwp_ws, dbias, B, H, W, Cs, Cout, tpw, (uint32_t)dy_b, (uint32_t)x_b, direct, Cin);
-        else
-            hipLaunchKernelGGL(conv3x3_wgrad_lds_kernel<8>, grid_lds, dim3(WG_THREADS), (size_t)(WG_DY_FLOATS + WgTile<8>::X_FLOATS) * 4, st,
-                               dy, x, dwp_ws, dbias, B, H, W, Cs, Cout, tpw, (uint32_t)dy_b, (uint32_t)x_b, direct, Cin);
+        d.dw_direct = direct;
+        if (lds16) hipLaunchKernelGGL(conv3x3_wgrad_lds_kernel<16>, grid_lds, dim3(WG_THREADS), (size_t)(WG_DY_FLOATS + WgTile<16>::X_FLOATS) * 4, st, d);
+        else hipLaunchKernelGGL(conv3x3_wgrad_lds_kernel<8>, grid_lds, dim3(WG_THREADS), (size_t)(WG_DY_FLOATS + WgTile<8>::X_FLOATS) * 4, st, d);
         SBGM_LAUNCH_CHECK();
         if (!direct) return unpack_or_queue(dwp_ws, dw_oihw, Cout, Cin, Cs, KH * KW, st);
         return 0;
