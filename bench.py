@@ -351,16 +351,18 @@ def train_secondary(dev, steps=10, warmup=3):
         opt.step()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    # ---- weight-gradient family, isolated launches ------------------------------------------------------------------------------
-    lib, tot_us, tot_fl, rows = N.lib(), 0.0, 0.0, []
+    # ---- weight-gradient family: each layer launched alone, and the whole family the way the step runs it (queued during the backward
+    # sweep, three batched launches + one layout launch at its end: sbgm_wgrad_defer bits 0 and 1) --------------------------------
+    lib, tot_us, tot_fl, rows, ops = N.lib(), 0.0, 0.0, [], []
     for (Bq, H, W, cs, cin, cout, k, stride, pad) in geoms:
         oh, ow = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
         dy, xx = torch.randn(Bq, oh, ow, cout, device=dev), torch.randn(Bq, H, W, cs, device=dev)
         dw, ws = torch.empty(cout, cin, k, k, device=dev), torch.zeros(k * k * cout * cs, device=dev)
 
-        def launch():
-            N.check(lib.sbgm_conv2d_wgrad(dy.data_ptr(), xx.data_ptr(), dw.data_ptr(), ws.data_ptr(), Bq, H, W, cs, cin, cout, k, k, stride, pad,
-                                          N.stream()))
+        def launch(dy=dy, xx=xx, dw=dw, ws=ws, g=(Bq, H, W, cs, cin, cout, k, stride, pad)):
+            N.check(lib.sbgm_conv2d_wgrad(dy.data_ptr(), xx.data_ptr(), dw.data_ptr(), ws.data_ptr(), g[0], g[1], g[2], g[3], g[4], g[5], g[6], g[6],
+                                          g[7], g[8], N.stream()))
+        ops.append((launch, ws))
         launch()
         gg = torch.cuda.CUDAGraph()
         with torch.cuda.graph(gg):
@@ -378,16 +380,47 @@ def train_secondary(dev, steps=10, warmup=3):
         tot_us += us
         tot_fl += fl
         rows.append({"B": Bq, "H": H, "W": W, "Cin": cin, "Cout": cout, "k": k, "stride": stride, "us": us, "tflops": fl / us * 1e-6})
+    iso_us = tot_us
+
+    def family():                                             # zero the slabs (the step's pool arrives zeroed), queue every layer, flush
+        for _, ws in ops:
+            ws.zero_()
+        prev = lib.sbgm_wgrad_defer(3)
+        try:
+            for launch, _ in ops:
+                launch()
+        finally:
+            lib.sbgm_wgrad_defer(prev)
+        N.check(lib.sbgm_wgrad_flush(N.stream()))
+    family()
+    gz, gf = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+    with torch.cuda.graph(gz):
+        for _, ws in ops:
+            ws.zero_()
+    with torch.cuda.graph(gf):
+        family()
+    best = None
+    for _ in range(5):
+        ev = [torch.cuda.Event(True) for _ in range(3)]
+        torch.cuda.synchronize()
+        ev[0].record(); gz.replay(); ev[1].record(); gf.replay(); ev[2].record()
+        torch.cuda.synchronize()
+        us = (ev[1].elapsed_time(ev[2]) - ev[0].elapsed_time(ev[1])) * 1e3          # the zero-fills are the pool's, not the family's
+        best = us if best is None else min(best, us)
+    tot_us = best
     ach = tot_fl / tot_us * 1e-6
     rows.sort(key=lambda r: -r["us"])
     return {"metric": "training samples/sec at 128x128 (loss_fn forward + backward as one hipGraph + native Adam), 1 GPU",
             "value": B * steps / dt, "unit": "samples/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
             "workload": "128x128 4-cond->1-target (C_in=5), batch 8 per GPU (BASELINE configs[2] per-GPU shape)",
             "final_loss": float(loss.detach()), "fp32_frac_of_step": 3 * 5.247e9 * B / (dt / steps) / (PEAK_FP32_TFLOPS * 1e12),
-            "wgrad_roofline": {"bound": "mfma", "kernel": "conv weight-gradient family (conv3x3_wgrad_lds / conv_tap_wgrad_lds / conv_wgrad + layout pass)",
+            "wgrad_roofline": {"bound": "mfma", "kernel": "conv weight-gradient family (conv3x3_wgrad_batched<16|8> / conv_tap_wgrad_batched / conv_wgrad + layout pass)",
                                "launches_per_step": len(geoms), "sum_us": tot_us, "gflop": tot_fl * 1e-9, "achieved": ach,
                                "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s", "frac": ach / PEAK_FP32_TFLOPS,
-                               "note": "each weight gradient of the step re-launched alone (10 per graph, HIP events); includes its zero-fill and OIHW layout pass",
+                               "isolated_sum_us": iso_us,
+                               "note": "sum_us / achieved: the step's weight gradients queued and flushed as the step runs them (batched launches per kernel "
+                                       "family + one OIHW layout launch; HIP events around a graph replay, zero-fills subtracted); isolated_sum_us / slowest: "
+                                       "each layer launched alone (10 per graph), including its zero-fill and layout pass",
                                "slowest": rows[:5]}}
 
 
