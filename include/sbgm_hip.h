@@ -234,7 +234,7 @@ typedef struct sbgm_pack_desc {
 int sbgm_conv_pack_weights_batched_blocks(int Cout, int KH, int KW, int c_pad);
 int sbgm_conv_pack_weights_batched(const sbgm_pack_desc* desc_dev, int n, int total_blocks, void* stream);
 /* Process-wide switch for the backward launchers (sbgm_conv2d_wgrad[_bias], sbgm_groupnorm_bwd, sbgm_batchnorm_bwd,
- * sbgm_layernorm_bwd's dgamma/dbeta, sbgm_samplesum's output, sbgm_batchnorm_train_fwd's sums): 1 = the caller
+ * sbgm_layernorm_bwd's dgamma/dbeta, sbgm_samplesum's output, sbgm_mha_core_bwd's dqkv, sbgm_batchnorm_train_fwd's sums): 1 = the caller
  * hands in already-zeroed scratch and the launchers skip their own memsets.  Returns the previous value. */
 int sbgm_set_scratch_prezeroed(int on);
 /* Deferred weight-gradient layout passes.  sbgm_conv2d_wgrad[_bias] accumulates most gradients in a [tap][Cout][c_pad] slab (ws)

@@ -1578,7 +1578,7 @@ int sbgm_launch_layernorm_bwd(const float* x, const float* dy, const float* gamm
 int sbgm_launch_mha_core_bwd(const float* qkv, const float* dout, float* dqkv, int B, int S, int C, int heads, hipStream_t st) {
     SBGM_CHECK(heads > 0 && C % heads == 0, "mha_bwd: C=%d heads=%d", C, heads);
     SBGM_CHECK((size_t)2 * 16 * S * 4 <= 150 * 1024, "mha_bwd: S=%d too long for the LDS-resident score rows", S);
-    { if (sbgm_zero_async(dqkv, (size_t)B * S * 3 * C * 4, st)) return 1; }
+    if (!sbgm_scratch_prezeroed) { if (sbgm_zero_async(dqkv, (size_t)B * S * 3 * C * 4, st)) return 1; }
     const int blocks = B * heads * ((S + 15) / 16);
     const int d = C / heads;
     const size_t lds_staged = ((size_t)(2 * S + 32) * (d + 1) + (size_t)32 * S) * 4;

@@ -257,7 +257,7 @@ def _sync_world():
 # Gradients that are accumulated with atomics and RETURNED to autograd (conv biases, LayerNorm gamma/beta, time-bias sums,
 # the weights of 1x1 convolutions / linears) are slices of one tensor that forward_train allocates zeroed — a fresh tensor per step, so a slice that lives on as
 # some parameter's .grad is never touched by a later step (unlike the scratch pool above, which is re-zeroed in place).
-_GRAD_FLOATS = 2 << 20
+_GRAD_FLOATS = 4 << 20
 _GRAD = {}             # device -> [tensor, offset]
 
 
@@ -802,8 +802,10 @@ class MHACoreFn(torch.autograd.Function):
         (qkv,) = ctx.saved_tensors
         B, S, Cc, heads = ctx.dims
         dout = dout.contiguous()
-        dqkv = torch.empty_like(qkv)
-        N.check(_L().sbgm_mha_core_bwd(qkv.data_ptr(), dout.data_ptr(), dqkv.data_ptr(), B, S, Cc, heads, _st()))
+        dqkv, zeroed = _grad_zeros(qkv.numel(), qkv.device)       # dK / dV are accumulated with atomics: a slice of the step's zeroed pool
+        dqkv = dqkv.view(qkv.shape)                              # saves the launcher's own memset (4 per step)
+        with _prezeroed(zeroed):
+            N.check(_L().sbgm_mha_core_bwd(qkv.data_ptr(), dout.data_ptr(), dqkv.data_ptr(), B, S, Cc, heads, _st()))
         return dqkv, None, None, None, None
 
 
