@@ -353,6 +353,7 @@ struct TapDesc {
     TapGeom g;
     int Cs, Cout, tiles_per_wg, Cin, gx, gy;
     uint32_t dy_bytes, x_bytes;
+    int big;               // 1: 128 x 128 blocks over 64-pixel tiles (tap_wgrad_body128), 0: 64 x 64 blocks over 128-pixel tiles
 };
 
 __device__ __forceinline__ void tap_wgrad_body(const TapDesc& a, const int bx, const int by) {
@@ -484,7 +485,132 @@ __device__ __forceinline__ void tap_wgrad_body(const TapDesc& a, const int bx, c
     }
 }
 
-__global__ __launch_bounds__(WG_THREADS) void conv_tap_wgrad_lds_kernel(const TapDesc a) { tap_wgrad_body(a, blockIdx.x, blockIdx.y); }
+// The same GEMM on 128 (co) x 128 (ci) blocks: wave w owns the 64 x 64 sub-block (w & 1, (w >> 1) & 1) over one half (w >> 2) of a
+// 64-pixel tile, so a staged byte feeds twice the MFMAs of the 64 x 64 form (32 instead of 16 flop per byte: that form re-reads dy once
+// per input-channel block and runs at the L2's rate) and only TWO partial copies fold through LDS.  Cs and Cout multiples of 128.
+constexpr int W2_PX = 64, W2_PS = 144;
+__device__ __forceinline__ void tap_wgrad_body128(const TapDesc& a, const int bx, const int by) {
+    const TapGeom g = a.g;
+    const int Cs = a.Cs, Cout = a.Cout;
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* dys = reinterpret_cast<float*>(smem_raw);                   // [64 px][144]
+    float* xs = dys + W2_PX * W2_PS;                                   // [64 px][144]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r16 = lane & 15, kq = lane >> 4;
+    const int wi = wave & 1, wj = (wave >> 1) & 1, ph = wave >> 2;
+    const int n_ci = Cs / 128, n_co = Cout / 128;
+    int blk = bx;
+    const int ci0 = (blk % n_ci) * 128; blk /= n_ci;
+    const int co0 = (blk % n_co) * 128;
+    const int tap = blk / n_co;
+    const int kh = tap / g.KW, kw0 = tap - kh * g.KW;
+    float* dwp = a.dwp + (size_t)tap * Cout * Cs;
+    const int n_tiles = (g.Mo + W2_PX - 1) / W2_PX;
+    const int t_begin = by * a.tiles_per_wg, t_end = min(n_tiles, t_begin + a.tiles_per_wg);
+    const __amdgpu_buffer_rsrc_t dr = make_rsrc(a.dy, a.dy_bytes);
+    const __amdgpu_buffer_rsrc_t xr = make_rsrc(a.x, a.x_bytes);
+    const bool shifted = g.stride != 1 || g.taps != 1 || g.pad != 0;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = a.dbias != nullptr && ci0 == 0 && tap == 0 && wj == 0;
+    float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+
+    constexpr int QPT = W2_PX * 32 / WG_THREADS;                       // 4 quads of each operand per thread
+    f32x4 rdy[QPT], rx[QPT];
+    auto tile_load = [&](int t) {
+#pragma unroll
+        for (int u = 0; u < QPT; ++u) {
+            const int q = tid + WG_THREADS * u;
+            const int p = t * W2_PX + (q >> 5), c4 = (q & 31) * 4;
+            bool ok = p < g.Mo;
+            uint32_t xoff = (uint32_t)(p * Cs + ci0 + c4);
+            rdy[u] = buf_load4(dr, ok ? (uint32_t)(p * Cout + co0 + c4) * 4u : 0x80000000u);
+            if (shifted) {
+                const int b = p / (g.OH * g.OW), r = p - b * (g.OH * g.OW);
+                const int oy = r / g.OW, ox = r - oy * g.OW;
+                const int iy = oy * g.stride - g.pad + kh, ix = ox * g.stride - g.pad + kw0;
+                xoff = (uint32_t)(((b * g.H + iy) * g.W + ix) * Cs + ci0 + c4);
+                ok = ok & ((unsigned)iy < (unsigned)g.H) & ((unsigned)ix < (unsigned)g.W);
+            }
+            rx[u] = buf_load4(xr, ok ? xoff * 4u : 0x80000000u);
+        }
+    };
+    auto tile_store = [&]() {
+#pragma unroll
+        for (int u = 0; u < QPT; ++u) {
+            const int q = tid + WG_THREADS * u;
+            *reinterpret_cast<f32x4*>(dys + (q >> 5) * W2_PS + (q & 31) * 4) = rdy[u];
+            *reinterpret_cast<f32x4*>(xs + (q >> 5) * W2_PS + (q & 31) * 4) = rx[u];
+        }
+    };
+    if (t_begin < t_end) tile_load(t_begin);
+    for (int t = t_begin; t < t_end; ++t) {
+        __syncthreads();
+        tile_store();
+        __syncthreads();
+        if (t + 1 < t_end) tile_load(t + 1);
+#pragma unroll
+        for (int s = 0; s < 8; ++s) {                                  // this wave's 32 pixels: 8 steps of 4 pixels
+            const int px = 32 * ph + 4 * s + kq;
+            float av[4], bv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                av[i] = dys[px * W2_PS + 64 * wi + 16 * i + r16];
+                bv[i] = xs[px * W2_PS + 64 * wj + 16 * i + r16];
+            }
+            if (do_bias) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bsum[i] += av[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[i], bv[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    if (do_bias) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            bsum[i] += __shfl_xor(bsum[i], 16, 64);
+            bsum[i] += __shfl_xor(bsum[i], 32, 64);
+            if (kq == 0) atomicAdd(a.dbias + co0 + 64 * wi + 16 * i + r16, bsum[i]);
+        }
+    }
+    // fold the two pixel halves: waves 4..7 hand their sub-block to waves 0..3 through LDS (16 KB each)
+    f32x4* red = reinterpret_cast<f32x4*>(smem_raw);                   // [4 sub-blocks][16 fragments][64 lanes]
+    __syncthreads();
+    if (ph == 1) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) red[((wave & 3) * 16 + i * 4 + j) * 64 + lane] = acc[i][j];
+    }
+    __syncthreads();
+    if (ph == 1) return;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 o = acc[i][j] + red[(wave * 16 + i * 4 + j) * 64 + lane];
+            const int ci = ci0 + 64 * wj + 16 * j + r16;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int co = co0 + 64 * wi + 16 * i + 4 * kq + e;
+                if (a.dw_direct) { if (ci < a.Cin) a.dw_direct[((size_t)co * a.Cin + ci) * g.taps + tap] = o[e]; }
+                else atomicAdd(dwp + (size_t)co * Cs + ci, o[e]);
+            }
+        }
+}
+
+__global__ __launch_bounds__(WG_THREADS) void conv_tap_wgrad_lds_kernel(const TapDesc a) {
+    if (a.big) tap_wgrad_body128(a, blockIdx.x, blockIdx.y);
+    else tap_wgrad_body(a, blockIdx.x, blockIdx.y);
+}
 
 // Batched form.  At training batch sizes a step has ~27 of these GEMMs (16 attention linears, the stride-2 and 1x1 shortcut convolutions,
 // the 3x3 layers on 4x4 maps, the two stems), 0.1-4 GFLOP each: launched one by one each fills the chip with ~256 workgroups that own a
@@ -502,7 +628,8 @@ __global__ __launch_bounds__(WG_THREADS) void conv_tap_wgrad_batched_kernel(cons
     k = __builtin_amdgcn_readfirstlane(k);
     const int rel = blockIdx.x - t.start[k];
     const int gx = t.d[k].gx;
-    tap_wgrad_body(t.d[k], rel % gx, rel / gx);
+    if (t.d[k].big) tap_wgrad_body128(t.d[k], rel % gx, rel / gx);
+    else tap_wgrad_body(t.d[k], rel % gx, rel / gx);
 }
 
 // stem slab [kh][Cout][kw][8] -> OIHW [Cout][Cin][KH][8]
@@ -1277,7 +1404,8 @@ static int tap_flush(hipStream_t st) {
     if (tap_set_attr()) return 1;
     static const int target = getenv("SBGM_TAP_BATCH_WGS") ? atoi(getenv("SBGM_TAP_BATCH_WGS")) : 1024;
     double work = 0.0;
-    for (auto& q : g_tap_queue) work += (double)q.d.gx * q.n_tiles;
+    auto cost = [](const TapQueued& q) { return (double)q.d.gx * q.n_tiles * (q.d.big ? 2.0 : 1.0); };   // MFMAs per tile-step: 128 vs 64 per wave
+    for (auto& q : g_tap_queue) work += cost(q);
     const size_t lds = (size_t)2 * W1_PX * W1_PS * 4;
     size_t i = 0;
     while (i < g_tap_queue.size()) {
@@ -1286,7 +1414,7 @@ static int tap_flush(hipStream_t st) {
         for (; i < g_tap_queue.size() && t.n < TAP_MAX; ++i) {
             TapQueued& q = g_tap_queue[i];
             TapDesc d = q.d;
-            const double share = (double)d.gx * q.n_tiles / work;
+            const double share = cost(q) / work;
             int gy = (int)std::lround(target * share / d.gx);
             gy = std::max(1, std::min(gy, q.n_tiles));
             d.tiles_per_wg = (q.n_tiles + gy - 1) / gy;
@@ -1440,8 +1568,10 @@ int sbgm_launch_conv_wgrad(const float* dy, const float* x, float* dw_oihw, floa
     if ((Cs % 64 == 0 || stem) && dy_b < (1ull << 31) && x_b < (1ull << 31) && getenv("SBGM_NO_LDS_WGRAD") == nullptr) {
         // one split-K GEMM per tap (1x1 / linear layers, and whatever the halo kernel above does not take)
         const int taps = stem ? KH : KH * KW;
-        const int blocks_x = taps * (Cout / 64) * (stem ? 1 : Cs / 64);
-        const int n_tiles = (M + W1_PX - 1) / W1_PX;
+        static const bool big_ok = getenv("SBGM_NO_TAP128") == nullptr;
+        const int big = big_ok && !stem && Cs % 128 == 0 && Cout % 128 == 0 ? 1 : 0;
+        const int blocks_x = big ? taps * (Cout / 128) * (Cs / 128) : taps * (Cout / 64) * (stem ? 1 : Cs / 64);
+        const int n_tiles = big ? (M + W2_PX - 1) / W2_PX : (M + W1_PX - 1) / W1_PX;
         const int wgs_y = std::max(1, std::min(n_tiles, (256 + blocks_x - 1) / blocks_x));      // one 8-wave workgroup per CU
         const int tpw = (n_tiles + wgs_y - 1) / wgs_y;
         const dim3 grid_lds(blocks_x, (n_tiles + tpw - 1) / tpw);
@@ -1452,7 +1582,7 @@ int sbgm_launch_conv_wgrad(const float* dy, const float* x, float* dw_oihw, floa
         const bool aliased = dwp_ws == dw_oihw;
         SBGM_CHECK(!aliased || (KH * KW == 1 && Cs == Cin), "wgrad: ws may alias dw only for 1x1 kernels with c_pad == Cin");
         const TapGeom tg{M, OH, OW, H, W, S, PAD, KW, KH * KW, stem ? 1 : 0};
-        TapDesc d{dy, x, dwp_ws, dbias, nullptr, tg, Cs, Cout, tpw, Cin, blocks_x, (int)grid_lds.y, (uint32_t)dy_b, (uint32_t)x_b};
+        TapDesc d{dy, x, dwp_ws, dbias, nullptr, tg, Cs, Cout, tpw, Cin, blocks_x, (int)grid_lds.y, (uint32_t)dy_b, (uint32_t)x_b, big};
         if (sbgm_wgrad_deferred & 2) {
             // queued: the slab may still be needed (the split is decided at the flush), so it is zeroed now unless it arrives zeroed
             if (!sbgm_scratch_prezeroed) { if (sbgm_zero_async(dwp_ws, n * 4, st)) return 1; }
