@@ -979,8 +979,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const float* __restr
 // (rows padded to d+1 floats: conflict-free column walks) instead of being re-read from global memory with one cache line per
 // lane — the scalar version spent almost all of its 145 us per launch on those uncoalesced reads.
 // =====================================================================================================================
-__global__ __launch_bounds__(256) void mha_core_bwd_lds_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
-                                                               float* __restrict__ dqkv, int B, int S, int C, int heads, float scale) {
+// LPQ = lanes per query row (16: 256 threads; 32: 512 threads, two waves per SIMD — the 256-token block is one workgroup per CU by its
+// LDS footprint, and with one wave per SIMD its dependent LDS-read / FMA chains ran at 89 us per launch)
+template <int LPQ>
+__global__ __launch_bounds__(16 * LPQ) void mha_core_bwd_lds_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                                    float* __restrict__ dqkv, int B, int S, int C, int heads, float scale) {
+    constexpr int NT = 16 * LPQ;
     extern __shared__ __attribute__((aligned(16))) char smem_raw[];
     const int d = C / heads, dp = d + 1;
     float* Ks = reinterpret_cast<float*>(smem_raw);      // [S][d+1]
@@ -998,14 +1002,14 @@ __global__ __launch_bounds__(256) void mha_core_bwd_lds_kernel(const float* __re
     const float* base = qkv + (size_t)b * S * rs + (size_t)h * d;
     float* dbase = dqkv + (size_t)b * S * rs + (size_t)h * d;
     const int dq4 = d >> 2;
-    for (int i = threadIdx.x; i < S * dq4; i += 256) {   // K and V rows of this (sample, head)
+    for (int i = threadIdx.x; i < S * dq4; i += NT) {   // K and V rows of this (sample, head)
         const int j = i / dq4, e = (i - j * dq4) * 4;
         const f32x4 kv = *reinterpret_cast<const f32x4*>(base + (size_t)j * rs + C + e);
         const f32x4 vv = *reinterpret_cast<const f32x4*>(base + (size_t)j * rs + 2 * C + e);
 #pragma unroll
         for (int t = 0; t < 4; ++t) { Ks[j * dp + e + t] = kv[t]; Vs[j * dp + e + t] = vv[t]; }
     }
-    for (int i = threadIdx.x; i < 16 * dq4; i += 256) {  // the 16 query rows and their output gradients
+    for (int i = threadIdx.x; i < 16 * dq4; i += NT) {  // the 16 query rows and their output gradients
         const int r = i / dq4, e = (i - r * dq4) * 4, qi = qb * 16 + r;
         f32x4 qv = {0.f, 0.f, 0.f, 0.f}, ov = qv;
         if (qi < S) {
@@ -1016,13 +1020,13 @@ __global__ __launch_bounds__(256) void mha_core_bwd_lds_kernel(const float* __re
         for (int t = 0; t < 4; ++t) { Qs[r * dp + e + t] = qv[t]; Os[r * dp + e + t] = ov[t]; }
     }
     __syncthreads();
-    const int qi_l = threadIdx.x >> 4, sub = threadIdx.x & 15;
+    const int qi_l = threadIdx.x / LPQ, sub = threadIdx.x % LPQ;
     const int qi = qb * 16 + qi_l;
     const bool q_ok = qi < S;
     const float* qrow = Qs + qi_l * dp;
     const float* dorow = Os + qi_l * dp;
     float mx = -INFINITY;
-    for (int j = sub; j < S; j += 16) {
+    for (int j = sub; j < S; j += LPQ) {
         const float* kr = Ks + j * dp;
         float sc = 0.f;
         for (int e = 0; e < d; ++e) sc = fmaf(qrow[e], kr[e], sc);
@@ -1031,14 +1035,14 @@ __global__ __launch_bounds__(256) void mha_core_bwd_lds_kernel(const float* __re
         mx = fmaxf(mx, sc);
     }
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+    for (int o = LPQ / 2; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
     float sum = 0.f;
-    for (int j = sub; j < S; j += 16) { const float pv = expf(Pm[qi_l * S + j] - mx); Pm[qi_l * S + j] = pv; sum += pv; }
+    for (int j = sub; j < S; j += LPQ) { const float pv = expf(Pm[qi_l * S + j] - mx); Pm[qi_l * S + j] = pv; sum += pv; }
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    for (int o = LPQ / 2; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
     const float inv = 1.f / sum;
     float delta = 0.f;
-    for (int j = sub; j < S; j += 16) {
+    for (int j = sub; j < S; j += LPQ) {
         const float pv = Pm[qi_l * S + j] * inv;
         const float* vr = Vs + j * dp;
         float dpv = 0.f;
@@ -1048,15 +1052,15 @@ __global__ __launch_bounds__(256) void mha_core_bwd_lds_kernel(const float* __re
         delta += pv * dpv;
     }
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) delta += __shfl_xor(delta, o, 64);
-    for (int j = sub; j < S; j += 16) {
+    for (int o = LPQ / 2; o > 0; o >>= 1) delta += __shfl_xor(delta, o, 64);
+    for (int j = sub; j < S; j += LPQ) {
         const float ds = q_ok ? Pm[qi_l * S + j] * (dSm[qi_l * S + j] - delta) * scale : 0.f;
         dSm[qi_l * S + j] = ds;
         if (!q_ok) Pm[qi_l * S + j] = 0.f;
     }
     __syncthreads();
     if (q_ok) {                                          // dQ[qi][e] = sum_j dS[qi][j] K[j][e]
-        for (int e = sub; e < d; e += 16) {
+        for (int e = sub; e < d; e += LPQ) {
             float acc = 0.f;
             for (int j = 0; j < S; ++j) acc = fmaf(dSm[qi_l * S + j], Ks[j * dp + e], acc);
             dbase[(size_t)qi * rs + e] = acc;
@@ -1714,9 +1718,16 @@ int sbgm_launch_mha_core_bwd(const float* qkv, const float* dout, float* dqkv, i
     const size_t lds_staged = ((size_t)(2 * S + 32) * (d + 1) + (size_t)32 * S) * 4;
     if (d % 4 == 0 && lds_staged <= 150 * 1024) {
         if (lds_staged > 64 * 1024)
-            SBGM_HIP(hipFuncSetAttribute((const void*)mha_core_bwd_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_staged));
-        hipLaunchKernelGGL(mha_core_bwd_lds_kernel, dim3(blocks), dim3(256), lds_staged, st, qkv, dout, dqkv, B, S, C, heads,
-                           1.0f / sqrtf((float)d));
+            SBGM_HIP(hipFuncSetAttribute((const void*)mha_core_bwd_lds_kernel<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_staged));
+        if (lds_staged > 64 * 1024)
+            SBGM_HIP(hipFuncSetAttribute((const void*)mha_core_bwd_lds_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_staged));
+        static const int wide_from = getenv("SBGM_MHA_BWD_WIDE_S") ? atoi(getenv("SBGM_MHA_BWD_WIDE_S")) : 16;
+        if (S >= wide_from)
+            hipLaunchKernelGGL(mha_core_bwd_lds_kernel<32>, dim3(blocks), dim3(512), lds_staged, st, qkv, dout, dqkv, B, S, C, heads,
+                               1.0f / sqrtf((float)d));
+        else
+            hipLaunchKernelGGL(mha_core_bwd_lds_kernel<16>, dim3(blocks), dim3(256), lds_staged, st, qkv, dout, dqkv, B, S, C, heads,
+                               1.0f / sqrtf((float)d));
         SBGM_LAUNCH_CHECK();
         return 0;
     }
