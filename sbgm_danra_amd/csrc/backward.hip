@@ -1081,6 +1081,169 @@ __global__ __launch_bounds__(16 * LPQ) void mha_core_bwd_lds_kernel(const float*
 }
 
 // =====================================================================================================================
+// Attention core backward on the fp32 matrix pipe (head dims that are multiples of 16; K, V of one (sample, head) in LDS).  Same
+// decomposition as the kernels around it — one workgroup per (sample, head, block of 16 queries), dK / dV by atomics — but all five
+// contractions are v_mfma_f32_16x16x4_f32 products on LDS-resident operands (rows padded by 4 floats: the (row = lane & 15,
+// element = 4 step + (lane >> 4)) reads of the A / B fragments fall on 64 distinct banks):
+//   S = Q K^T, dP = dO V^T      key blocks dealt round-robin to the 4 waves, d/4 MFMA steps each, both products share the loop
+//   P = softmax(S * scale), dS = P * (dP - sum_j P dP) * scale        16 lanes per query row, in LDS
+//   dQ = dS K                    one 16 x 16 output block per wave (d/16 blocks), S/4 steps
+//   dK += dS^T Q, dV += P^T dO   per key block and 16-wide slice of d: 4 steps (the 16 queries), accumulators straight to the atomics
+// The scalar kernels above / below spent 65 us on the 256-token block of a C3 training step (B = 8) where this form needs ~15.
+// =====================================================================================================================
+template <int D>
+__global__ __launch_bounds__(256) void mha_core_bwd_mfma_kernel(const float* __restrict__ qkv, const float* __restrict__ dout,
+                                                                float* __restrict__ dqkv, int B, int S, int C, int heads, float scale, int G) {
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    constexpr int DP = D + 4, DQ4 = D / 4;
+    constexpr int NBW = 128 / D;                         // key blocks per wave at the largest S the LDS holds (4, 2, 1 for d = 32, 64, 128)
+    const int S16 = (S + 15) & ~15, SP = S16 + 4, NB = S16 >> 4;
+    float* Ks = reinterpret_cast<float*>(smem_raw);      // [S16][DP]
+    float* Vs = Ks + (size_t)S16 * DP;                   // [S16][DP]
+    float* Qs = Vs + (size_t)S16 * DP;                   // [16][DP]
+    float* Os = Qs + 16 * DP;                            // [16][DP]   dO rows
+    float* Pm = Os + 16 * DP;                            // [16][SP]   scores, then P
+    float* Dm = Pm + 16 * SP;                            // [16][SP]   dP, then dS * scale
+    const int qblocks = (S + 15) / 16, qgroups = (qblocks + G - 1) / G;
+    int w = blockIdx.x;
+    const int qg = w % qgroups; w /= qgroups;
+    const int h = w % heads;
+    const int b = w / heads;
+    const size_t rs = 3 * (size_t)C;
+    const float* base = qkv + (size_t)b * S * rs + (size_t)h * D;
+    float* dbase = dqkv + (size_t)b * S * rs + (size_t)h * D;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 15, kq = lane >> 4;
+    for (int i = tid; i < S16 * DQ4; i += 256) {         // K and V rows of this (sample, head), once for the G query blocks; rows past S are zero
+        const int j = i / DQ4, e = (i - j * DQ4) * 4;
+        f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = kv;
+        if (j < S) {
+            kv = *reinterpret_cast<const f32x4*>(base + (size_t)j * rs + C + e);
+            vv = *reinterpret_cast<const f32x4*>(base + (size_t)j * rs + 2 * C + e);
+        }
+        *reinterpret_cast<f32x4*>(Ks + j * DP + e) = kv;
+        *reinterpret_cast<f32x4*>(Vs + j * DP + e) = vv;
+    }
+    // dK / dV of this wave's key blocks, accumulated over the workgroup's query blocks: [key block slot][16-wide slice of d]
+    f32x4 ak[NBW][D / 16], av[NBW][D / 16];
+#pragma unroll
+    for (int u = 0; u < NBW; ++u)
+#pragma unroll
+        for (int eb = 0; eb < D / 16; ++eb) { ak[u][eb] = f32x4{0.f, 0.f, 0.f, 0.f}; av[u][eb] = ak[u][eb]; }
+
+    for (int gq = 0; gq < G; ++gq) {
+        const int qb = qg * G + gq;
+        if (qb >= qblocks) break;                         // uniform
+        for (int i = tid; i < 16 * DQ4; i += 256) {      // the 16 query rows and their output gradients
+            const int rr = i / DQ4, e = (i - rr * DQ4) * 4, qi = qb * 16 + rr;
+            f32x4 qv = {0.f, 0.f, 0.f, 0.f}, ov = qv;
+            if (qi < S) {
+                qv = *reinterpret_cast<const f32x4*>(base + (size_t)qi * rs + e);
+                ov = *reinterpret_cast<const f32x4*>(dout + ((size_t)b * S + qi) * C + (size_t)h * D + e);
+            }
+            *reinterpret_cast<f32x4*>(Qs + rr * DP + e) = qv;
+            *reinterpret_cast<f32x4*>(Os + rr * DP + e) = ov;
+        }
+        __syncthreads();
+        // ---- S = Q K^T * scale and dP = dO V^T: lane ends up with rows 4 kq + reg (queries), column r (key) of a key block ---
+        for (int jb = wave; jb < NB; jb += 4) {
+            f32x4 as = {0.f, 0.f, 0.f, 0.f}, ap = as;
+            const float* kr = Ks + (jb * 16 + r) * DP + kq;
+            const float* vr = Vs + (jb * 16 + r) * DP + kq;
+            const float* qr = Qs + r * DP + kq;
+            const float* orow = Os + r * DP + kq;
+#pragma unroll 4
+            for (int st = 0; st < DQ4; ++st) {
+                as = __builtin_amdgcn_mfma_f32_16x16x4f32(qr[4 * st], kr[4 * st], as, 0, 0, 0);
+                ap = __builtin_amdgcn_mfma_f32_16x16x4f32(orow[4 * st], vr[4 * st], ap, 0, 0, 0);
+            }
+            const bool key_ok = jb * 16 + r < S;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                Pm[(4 * kq + g) * SP + jb * 16 + r] = key_ok ? as[g] * scale : -INFINITY;
+                Dm[(4 * kq + g) * SP + jb * 16 + r] = ap[g];
+            }
+        }
+        __syncthreads();
+        // ---- softmax rows and dS -----------------------------------------------------------------------------------------------
+        {
+            const int qi_l = tid >> 4, sub = tid & 15;
+            const bool q_ok = qb * 16 + qi_l < S;
+            float* prow = Pm + qi_l * SP;
+            float* drow = Dm + qi_l * SP;
+            float mx = -INFINITY;
+            for (int j = sub; j < S16; j += 16) mx = fmaxf(mx, prow[j]);
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
+            float sum = 0.f;
+            for (int j = sub; j < S16; j += 16) { const float pv = expf(prow[j] - mx); prow[j] = pv; sum += pv; }     // exp(-inf) = 0 past S
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+            const float inv = 1.f / sum;
+            float delta = 0.f;
+            for (int j = sub; j < S16; j += 16) { const float pv = prow[j] * inv; prow[j] = pv; delta += pv * drow[j]; }
+#pragma unroll
+            for (int o = 8; o > 0; o >>= 1) delta += __shfl_xor(delta, o, 64);
+            for (int j = sub; j < S16; j += 16) {
+                const float pv = prow[j];
+                drow[j] = q_ok ? pv * (drow[j] - delta) * scale : 0.f;
+                if (!q_ok) prow[j] = 0.f;
+            }
+        }
+        __syncthreads();
+        // ---- dQ = dS K: one 16 x 16 block of (queries x head dim) per wave --------------------------------------------------------
+        for (int eb = wave; eb < D / 16; eb += 4) {
+            f32x4 aq = {0.f, 0.f, 0.f, 0.f};
+            const float* dr = Dm + r * SP + kq;
+            const float* kc = Ks + kq * DP + eb * 16 + r;
+            for (int st = 0; st < S16 / 4; ++st) aq = __builtin_amdgcn_mfma_f32_16x16x4f32(dr[4 * st], kc[(size_t)4 * st * DP], aq, 0, 0, 0);
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int qi = qb * 16 + 4 * kq + g;
+                if (qi < S) dbase[(size_t)qi * rs + eb * 16 + r] = aq[g];
+            }
+        }
+        // ---- dK += dS^T Q, dV += P^T dO: this wave's key blocks, 16-wide slices of the head dim, into the running accumulators -------
+#pragma unroll
+        for (int u = 0; u < NBW; ++u) {
+            const int jb = wave + 4 * u;
+            if (jb < NB) {                                // uniform
+                f32x4 ds4, p4;                           // A fragments of the 4 steps (queries 4 st + kq), shared by every slice
+#pragma unroll
+                for (int st = 0; st < 4; ++st) {
+                    ds4[st] = Dm[(4 * st + kq) * SP + jb * 16 + r];
+                    p4[st] = Pm[(4 * st + kq) * SP + jb * 16 + r];
+                }
+#pragma unroll
+                for (int eb = 0; eb < D / 16; ++eb)
+#pragma unroll
+                    for (int st = 0; st < 4; ++st) {
+                        ak[u][eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(ds4[st], Qs[(4 * st + kq) * DP + eb * 16 + r], ak[u][eb], 0, 0, 0);
+                        av[u][eb] = __builtin_amdgcn_mfma_f32_16x16x4f32(p4[st], Os[(4 * st + kq) * DP + eb * 16 + r], av[u][eb], 0, 0, 0);
+                    }
+            }
+        }
+        __syncthreads();                                  // Qs / Os / Pm / Dm are rewritten by the next query block
+    }
+#pragma unroll
+    for (int u = 0; u < NBW; ++u) {
+        const int jb = wave + 4 * u;
+        if (jb >= NB) continue;
+#pragma unroll
+        for (int eb = 0; eb < D / 16; ++eb)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int key = jb * 16 + 4 * kq + g;
+                if (key < S) {
+                    atomicAdd(dbase + (size_t)key * rs + C + eb * 16 + r, ak[u][eb][g]);
+                    atomicAdd(dbase + (size_t)key * rs + 2 * C + eb * 16 + r, av[u][eb][g]);
+                }
+            }
+    }
+}
+
+// =====================================================================================================================
 // Attention core backward.  One workgroup per (sample, head, block of 16 queries); 16 lanes per query.
 //   P = softmax(q k^T * scale);  dV += P^T dO;  dP = dO V^T;  dS = P*(dP - sum_j P dP);  dQ = dS K * scale;  dK += dS^T Q * scale
 // dK/dV are accumulated with fp32 atomics (every query block contributes to all keys).
@@ -1715,6 +1878,31 @@ int sbgm_launch_mha_core_bwd(const float* qkv, const float* dout, float* dqkv, i
     if (!sbgm_scratch_prezeroed) { if (sbgm_zero_async(dqkv, (size_t)B * S * 3 * C * 4, st)) return 1; }
     const int blocks = B * heads * ((S + 15) / 16);
     const int d = C / heads;
+    {   // matrix-pipe form: head dim 32 / 64 / 128, K and V of a (sample, head) LDS-resident, <= 128 / d key blocks per wave
+        const int S16 = (S + 15) & ~15;
+        const size_t lds_mfma = ((size_t)(2 * S16 + 32) * (d + 4) + (size_t)32 * (S16 + 4)) * 4;
+        static const bool mfma_ok = getenv("SBGM_NO_MHA_BWD_MFMA") == nullptr;
+        if (mfma_ok && (d == 32 || d == 64 || d == 128) && lds_mfma <= 150 * 1024 && S16 / 16 <= 4 * (128 / d)) {
+            const float scale = 1.0f / sqrtf((float)d);
+            // G query blocks per workgroup share one staging of K / V and one round of dK / dV atomics: as many as still leave every CU a
+            // workgroup (the 256-token block of a batch-8 step: 512 -> 256 workgroups of 2 query blocks)
+            static const int gmax = getenv("SBGM_MHA_BWD_G") ? atoi(getenv("SBGM_MHA_BWD_G")) : 0;
+            const int qblocks = (S + 15) / 16;
+            int G = gmax > 0 ? gmax : std::max(1, blocks / 256);
+            G = std::max(1, std::min(G, qblocks));
+            const int grid = B * heads * ((qblocks + G - 1) / G);
+#define SBGM_MB(DD)                                                                                                              \
+    {                                                                                                                              \
+        static bool attr = false;                                                                                                  \
+        if (!attr) { SBGM_HIP(hipFuncSetAttribute((const void*)mha_core_bwd_mfma_kernel<DD>, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024)); attr = true; } \
+        hipLaunchKernelGGL(mha_core_bwd_mfma_kernel<DD>, dim3(grid), dim3(256), lds_mfma, st, qkv, dout, dqkv, B, S, C, heads, scale, G);  \
+    }
+            if (d == 32) SBGM_MB(32) else if (d == 64) SBGM_MB(64) else SBGM_MB(128)
+#undef SBGM_MB
+            SBGM_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     const size_t lds_staged = ((size_t)(2 * S + 32) * (d + 1) + (size_t)32 * S) * 4;
     if (d % 4 == 0 && lds_staged <= 150 * 1024) {
         if (lds_staged > 64 * 1024)
