@@ -1402,8 +1402,17 @@ __global__ __launch_bounds__(256) void cout1_bwd_weight_kernel(const float* __re
                                                                float* __restrict__ dbias, int B, int H, int W, int C,
                                                                int rows_per_block) {
     __shared__ float red[9 * 1024];                                  // [tap][stripe][C], stripes * C <= 1024
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    float* gs = reinterpret_cast<float*>(smem_raw);                   // upstream gradient rows r0 - 1 .. r1 of the [B*H][W] plane
     const int nrows = B * H;
     const int r0 = blockIdx.x * rows_per_block, r1 = min(nrows, r0 + rows_per_block);
+    // the 9 values of g around a pixel used to be 9 scalar global loads per activation quad (a vector-memory instruction costs the wave
+    // 100+ cycles of issue: 49 us for this 33 MB pass); they now come from LDS
+    for (int i = threadIdx.x; i < (r1 - r0 + 2) * W; i += blockDim.x) {
+        const int grow = r0 - 1 + i / W;
+        gs[i] = (unsigned)grow < (unsigned)nrows ? dout[(size_t)grow * W + (i % W)] : 0.f;
+    }
+    __syncthreads();
     const int cq = C >> 2, q = threadIdx.x % cq, stripe = threadIdx.x / cq, lanes_px = 256 / cq;
     f32x4 acc[9];
 #pragma unroll
@@ -1412,7 +1421,7 @@ __global__ __launch_bounds__(256) void cout1_bwd_weight_kernel(const float* __re
         for (int row = r0; row < r1; ++row) {
             const int b = row / H, iy = row - b * H;
             const float inv = t ? 1.f / sigma_of(t[b], sigma) : 1.f;
-            const float* drow = dout + (size_t)b * H * W;
+            const float* drow = gs + (size_t)(b * H - (r0 - 1)) * W;   // row oy of image b sits at global row b*H + oy
             for (int ix = stripe; ix < W; ix += lanes_px) {
                 const f32x4 av = *reinterpret_cast<const f32x4*>(a + (((size_t)b * H + iy) * W + ix) * C + q * 4) * inv;
 #pragma unroll
@@ -1970,7 +1979,7 @@ int sbgm_launch_cout1_bwd(const float* dout, const float* a, const float* w_tap_
     { if (sbgm_zero_async(dw_tap_c, (size_t)9 * C * 4, st)) return 1; }
     { if (sbgm_zero_async(dbias, 4, st)) return 1; }
     const int rows = B * H, rpb = std::max(1, rows / 256);
-    hipLaunchKernelGGL(cout1_bwd_weight_kernel, dim3((rows + rpb - 1) / rpb), dim3(256), 0, st, dout, a, t, sigma, dw_tap_c, dbias, B, H,
+    hipLaunchKernelGGL(cout1_bwd_weight_kernel, dim3((rows + rpb - 1) / rpb), dim3(256), (size_t)(rpb + 2) * W * 4, st, dout, a, t, sigma, dw_tap_c, dbias, B, H,
                        W, C, rpb);
     SBGM_LAUNCH_CHECK();
     return 0;
