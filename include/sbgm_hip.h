@@ -4,7 +4,7 @@
  * Boundary: this library sits between the reference's Python layer L1 (sbgm/score_unet.py, sbgm/score_sampling.py)
  * and what used to be torch.nn ops.  Plain pointers and sizes only; every pointer is a DEVICE pointer unless said
  * otherwise; every call enqueues on `stream` (a hipStream_t passed as void*) and returns without synchronising (the exceptions —
- * sbgm_sampler_run, the tuning / profiling calls — say so where they are declared).
+ * the tuning / profiling calls, a sampler's first call of a shape — say so where they are declared).
  * Return value: 0 = ok, non-zero = error (text via sbgm_last_error()).  The Python mirror raises RuntimeError.
  *
  * Tensor conventions at the boundary are the reference's: NCHW contiguous fp32, t float [B], y int64 [B] with
@@ -118,10 +118,12 @@ typedef struct sbgm_sampler_args {
     const int* tile_origins;
     int domain_w;
 } sbgm_sampler_args;
-/* Enqueues the whole reverse-SDE loop.  Exception to the rule in the header of this file: the call BLOCKS THE HOST once, after
- * enqueuing the upload of its step table (a host buffer it owns), until everything previously enqueued on `stream` has finished
- * (an earlier sampler run included); a guided run also waits at its end (it frees per-call condition copies).  The loop and the
- * copy into `out` are otherwise only enqueued.  The handle's workspace is the engine's: the caller passes no scratch memory. */
+/* Enqueues the whole reverse-SDE loop and returns: the step table and the initial state are uploaded from pinned memory the handle owns,
+ * so a steady-state call waits for nothing (two runs enqueued back to back simply execute in stream order).  It blocks the host only
+ * in these cases: the first call of a (B, H, W) the handle has not seen (one measuring evaluation, then the workspace is sized), a call
+ * that has to grow or trim the workspace or the step table (hipFree / hipMalloc), a change of the captured step's key while a replay of
+ * the old graph is still executing, and guided runs (cfg_enabled), which free per-call condition copies at their end.  The handle's
+ * workspace is the engine's: the caller passes no scratch memory. */
 int sbgm_sampler_run(sbgm_model* m, const sbgm_sampler_args* a, void* stream);
 
 /* Conv autotuning: time the tile / split-K candidates of every convolution of the (B,H,W) plan once and keep the

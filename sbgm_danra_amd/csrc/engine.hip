@@ -93,6 +93,12 @@ struct sbgm_model {
     SamplerState* d_state = nullptr;
     StepScalars* d_table = nullptr;
     int table_cap = 0;
+    // pinned host staging of a run's step table + initial state: the upload is a true asynchronous copy, so sbgm_sampler_run does not
+    // have to wait for it (or for anything enqueued before it); ev_stage guards the buffer against the next call's rewrite
+    char* h_stage = nullptr;
+    size_t h_stage_bytes = 0;
+    hipEvent_t ev_stage = nullptr;
+    bool stage_pending = false;
     std::map<ConvOpKey, ConvTile> tuned;
     ConvTile last_tile{};                   // tile of the most recent conv() (tells the caller whether GroupNorm statistics were fused)
     bool tuning = false;
@@ -116,6 +122,7 @@ struct sbgm_model {
     hipGraphExec_t step_exec = nullptr;
     unsigned long long plan_gen = 0;         // bumped whenever the tile table changes (the captured launches embed tile choices)
     void drop_step_graph() {
+        if (step_exec && graph_stream) (void)hipStreamSynchronize(graph_stream);      // a replay of it may still be executing
         if (step_exec) (void)hipGraphExecDestroy(step_exec);
         if (step_graph) (void)hipGraphDestroy(step_graph);
         step_exec = nullptr;
@@ -128,6 +135,8 @@ struct sbgm_model {
         if (ws) (void)hipFree(ws);
         if (d_state) (void)hipFree(d_state);
         if (d_table) (void)hipFree(d_table);
+        if (h_stage) (void)hipHostFree(h_stage);
+        if (ev_stage) (void)hipEventDestroy(ev_stage);
         if (graph_stream) (void)hipStreamDestroy(graph_stream);
         if (ev_in) (void)hipEventDestroy(ev_in);
         if (ev_out) (void)hipEventDestroy(ev_out);
@@ -896,8 +905,20 @@ int sbgm_model::sampler(const sbgm_sampler_args& a, hipStream_t caller) {
     const int BE = guided ? 2 * B : B;                     // samples per network evaluation
     const size_t per = (size_t)H * W, n = (size_t)B * per;
     SBGM_CHECK(ws_need(BE, H, W, a.bn_train) <= ws_bytes, "sampler: workspace not prepared for B=%d H=%d W=%d", BE, H, W);
-    // ---- per-step scalars on the host, in the reference's precision --------------------------------------------------
-    std::vector<StepScalars> tab(N);
+    // ---- per-step scalars on the host, in the reference's precision, written into the pinned staging buffer ---------------------
+    const size_t stage_need = sizeof(StepScalars) * (size_t)N + sizeof(SamplerState);
+    if (stage_pending) {                                   // the previous call's upload still reads the buffer (normally long done)
+        SBGM_HIP(hipEventSynchronize(ev_stage));
+        stage_pending = false;
+    }
+    if (h_stage_bytes < stage_need) {
+        if (h_stage) SBGM_HIP(hipHostFree(h_stage));
+        h_stage = nullptr;
+        h_stage_bytes = std::max(stage_need, sizeof(StepScalars) * (size_t)4096 + sizeof(SamplerState));
+        SBGM_HIP(hipHostMalloc(reinterpret_cast<void**>(&h_stage), h_stage_bytes, hipHostMallocDefault));
+    }
+    if (!ev_stage) SBGM_HIP(hipEventCreateWithFlags(&ev_stage, hipEventDisableTiming));
+    StepScalars* tab = reinterpret_cast<StepScalars*>(h_stage);
     const float sig = cfg.sigma;
     if (a.kind == SBGM_SAMPLER_EM) {                       // score_sampling.py:96-97, :102-103, :124-125
         const std::vector<float> ts = linspace_f32(1.0f, a.eps, N);
@@ -918,6 +939,7 @@ int sbgm_model::sampler(const sbgm_sampler_args& a, hipStream_t caller) {
             tab[i] = StepScalars{tf, g * g, dt, sqrtf((g * g) * dt), (float)ts[std::min(i + 1, N - 1)]};
         }
     }
+    const float t_first = tab[0].t;
     if (table_cap < N) {
         if (d_table) SBGM_HIP(hipFree(d_table));
         d_table = nullptr;
@@ -925,10 +947,12 @@ int sbgm_model::sampler(const sbgm_sampler_args& a, hipStream_t caller) {
         SBGM_HIP(hipMalloc(&d_table, sizeof(StepScalars) * cap));
         table_cap = cap;
     }
-    SBGM_HIP(hipMemcpyAsync(d_table, tab.data(), sizeof(StepScalars) * N, hipMemcpyHostToDevice, st));
-    const SamplerState state0{0ull, 0ull, (unsigned long long)a.seed, (unsigned long long)N};
-    SBGM_HIP(hipMemcpyAsync(d_state, &state0, sizeof(SamplerState), hipMemcpyHostToDevice, st));
-    SBGM_HIP(hipStreamSynchronize(st));                   // tab / state0 are stack-lifetime host buffers
+    SamplerState* state0 = reinterpret_cast<SamplerState*>(h_stage + sizeof(StepScalars) * (size_t)N);
+    *state0 = SamplerState{0ull, 0ull, (unsigned long long)a.seed, (unsigned long long)N};
+    SBGM_HIP(hipMemcpyAsync(d_table, tab, sizeof(StepScalars) * N, hipMemcpyHostToDevice, st));
+    SBGM_HIP(hipMemcpyAsync(d_state, state0, sizeof(SamplerState), hipMemcpyHostToDevice, st));
+    SBGM_HIP(hipEventRecord(ev_stage, st));               // no host wait: the copies read pinned memory this handle owns
+    stage_pending = true;
 
     // persistent sampler buffers live at the top of the workspace, the forward uses the rest
     // layout (BE = B, or 2B with guidance): x [BE*per] (rows B.. mirror rows 0..B-1), score [BE*per], x_mean [B*per]
@@ -990,7 +1014,7 @@ int sbgm_model::sampler(const sbgm_sampler_args& a, hipStream_t caller) {
         nm = NoiseMap{a.tile_origins, H, W / 4, (a.domain_w + 3) / 4};
     }
     if (sbgm_launch_init_noise(xs, std1, next_z(), a.seed, d_state, 0, n, st, nm)) return 1;
-    if (sbgm_launch_fill_t(t_dev, tab[0].t, BE, st)) return 1;
+    if (sbgm_launch_fill_t(t_dev, t_first, BE, st)) return 1;
     const float snr_nn = (float)((double)a.snr * std::sqrt((double)per));     // snr * sqrt(prod(x.shape[1:])) (:202-203)
 
     // one (possibly guided) score evaluation of the current x into score[0 .. n)
