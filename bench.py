@@ -166,8 +166,13 @@ def sampling_secondary(dev, B, HW, sampler_key, steps, warmup, n_cond=1):
     sampler = S.Euler_Maruyama_sampler if sampler_key == "em" else S.pc_sampler
     evals = 1 if sampler_key == "em" else 2
     kw = dict(batch_size=B, device=dev, img_size=HW, cond_img=cond, use_graph=True, seed=1234)
+    tw = time.perf_counter()
     sampler(net, S.marginal_prob_std_fn, S.diffusion_coeff_fn, num_steps=max(2, warmup), **kw)
     torch.cuda.synchronize()
+    warm_s = time.perf_counter() - tw                    # untimed steps up to CLOCK_WARM_S of sampling, as for the headline
+    if warm_s < CLOCK_WARM_S:
+        sampler(net, S.marginal_prob_std_fn, S.diffusion_coeff_fn, num_steps=max(2, int((CLOCK_WARM_S - warm_s) / max(warm_s / max(2, warmup), 1e-4)) + 1), **kw)
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     out = sampler(net, S.marginal_prob_std_fn, S.diffusion_coeff_fn, num_steps=steps, **kw)
     torch.cuda.synchronize()
@@ -342,8 +347,14 @@ def train_secondary(dev, steps=10, warmup=3):
     opt.zero_grad(set_to_none=True)
     with torch.cuda.graph(graph):
         loss = fwd_bwd()
+    tw = time.perf_counter()
     for _ in range(warmup):
         graph.replay()
+        opt.step()
+    torch.cuda.synchronize()
+    warm_s = time.perf_counter() - tw
+    for _ in range(int((CLOCK_WARM_S - warm_s) / max(warm_s / max(1, warmup), 1e-4)) + 1 if warm_s < CLOCK_WARM_S else 0):
+        graph.replay()                                   # untimed: steady device clocks, as for the headline
         opt.step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
