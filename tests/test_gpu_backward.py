@@ -227,6 +227,56 @@ def test_deferred_weight_gradient_layout_passes():
         assert maxrel(b.cpu(), a.cpu()) < 1e-6 and not torch.isnan(b).any()  # atomically accumulated slabs: order may differ in the last bit
 
 
+def test_deferred_weight_gradient_gemms_run_as_batched_launches():
+    """sbgm_wgrad_defer bit 1: the weight-gradient GEMMs themselves are queued (3x3 halo kernel on 16x16 tiles and on 8x8 maps, the per-tap
+    kernel in its 64x64 and 128x128 block forms, a linear whose slab IS the gradient, the 8-channel stem) and run at the flush as one
+    launch per kernel family with pixel splits chosen across the batch; results equal the immediate launches (atomics: last-bit order)
+    and torch's conv2d weight gradients"""
+    lib = N.lib()
+    #        B  cin   H  cout k  s  p   cs
+    cases = [(2, 64, 32, 64, 3, 1, 1, 64), (2, 128, 16, 128, 3, 1, 1, 128), (4, 256, 8, 256, 3, 1, 1, 256), (2, 64, 16, 128, 3, 2, 1, 64),
+             (2, 128, 16, 256, 3, 2, 1, 128), (2, 512, 4, 512, 3, 1, 1, 512), (1, 5, 32, 64, 8, 2, 3, 8), (2, 64, 16, 64, 8, 2, 3, 64),
+             (2, 128, 16, 256, 1, 2, 0, 128)]
+    linears = [(300, 256, 768), (128, 512, 512), (2048, 128, 128)]            # (tokens, Cin, Cout): ws aliases dw
+    keep, res = [], {0: [], 3: []}
+    for defer in (0, 3):
+        prev = lib.sbgm_wgrad_defer(defer)
+        for i, (B, cin, H, cout, k, s, p, cs) in enumerate(cases):
+            oh = (H + 2 * p - k) // s + 1
+            x = torch.zeros(B, H, H, cs)
+            x[..., :cin] = rnd(B, H, H, cin, seed=i)
+            dy = rnd(B, oh, oh, cout, seed=50 + i)
+            xd, dyd = x.cuda(), dy.cuda()
+            dw, ws = torch.zeros(cout, cin, k, k, device="cuda"), torch.zeros(k * k * cout * cs, device="cuda")
+            db = torch.zeros(cout, device="cuda")
+            N.check(lib.sbgm_conv2d_wgrad_bias(dyd.data_ptr(), xd.data_ptr(), dw.data_ptr(), db.data_ptr(), ws.data_ptr(), B, H, H, cs, cin,
+                                               cout, k, k, s, p, N.stream()))
+            keep += [xd, dyd, ws]
+            res[defer].append((dw, db, x[..., :cin], dy, s, p))
+        for i, (M, cin, cout) in enumerate(linears):
+            x, dy = rnd(M, cin, seed=80 + i), rnd(M, cout, seed=90 + i)
+            xd, dyd = x.cuda(), dy.cuda()
+            dw = torch.zeros(cout, cin, 1, 1, device="cuda")
+            N.check(lib.sbgm_conv2d_wgrad(dyd.data_ptr(), xd.data_ptr(), dw.data_ptr(), dw.data_ptr(), 1, 1, M, cin, cin, cout, 1, 1, 1, 0,
+                                          N.stream()))
+            keep += [xd, dyd]
+            res[defer].append((dw, None, x.view(1, 1, M, cin), dy.view(1, 1, M, cout), 1, 0))
+        lib.sbgm_wgrad_defer(prev)
+    assert lib.sbgm_wgrad_flush_pending() >= len(cases) + len(linears) - 1    # (a layer the general kernel serves is not queued)
+    torch.cuda.synchronize()
+    assert all(float(d[0].abs().max()) == 0.0 for d in res[3])               # nothing has run yet
+    N.check(lib.sbgm_wgrad_flush(N.stream()))
+    assert lib.sbgm_wgrad_flush_pending() == 0
+    for (a, ab, x, dy, s, p), (b, bb, _, _, _, _) in zip(res[0], res[3]):
+        assert maxrel(b.cpu(), a.cpu()) < 1e-5
+        if ab is not None:
+            assert maxrel(bb.cpu(), ab.cpu()) < 1e-5
+        xr = nchw(x).clone().requires_grad_(False)
+        wr = torch.zeros(b.shape, requires_grad=True)
+        F.conv2d(xr, wr, None, s, p).backward(nchw(dy))
+        assert maxrel(b.cpu(), wr.grad) < GT
+
+
 def test_final_conv_backward():
     B, Cc, H, W = 2, 64, 10, 12
     a, w, b, t, go = rnd(B, Cc, H, W), rnd(1, Cc, 3, 3, seed=1) * 0.05, rnd(1, seed=2), torch.tensor([0.05, 0.8]), rnd(B, 1, H, W, seed=3)
