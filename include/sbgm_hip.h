@@ -118,7 +118,8 @@ typedef struct sbgm_sampler_args {
     const int* tile_origins;
     int domain_w;
 } sbgm_sampler_args;
-/* Enqueues the whole reverse-SDE loop and returns: the step table and the initial state are uploaded from pinned memory the handle owns,
+/* Enqueues the whole reverse-SDE loop on `stream` and returns (with use_graph the step is captured once on a private stream and its
+ * num_steps replays are launched on `stream`): the step table and the initial state are uploaded from pinned memory the handle owns,
  * so a steady-state call waits for nothing (two runs enqueued back to back simply execute in stream order).  It blocks the host only
  * in these cases: the first call of a (B, H, W) the handle has not seen (one measuring evaluation, then the workspace is sized), a call
  * that has to grow or trim the workspace or the step table (hipFree / hipMalloc), a change of the captured step's key while a replay of
