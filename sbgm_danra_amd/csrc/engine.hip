@@ -398,25 +398,74 @@ int sbgm_model::fold_bn(hipStream_t st) {
     return 0;
 }
 
-// Static heuristic: fill ~2 waves per SIMD (2048 waves) with the largest tile that gets there; use split-K for the
-// small-spatial layers whose M*Cout is too small even with small tiles.
+// Static choice for a convolution the autotuner has not timed.  It follows what the tuner picks on the BASELINE shapes and on
+// small batches (profiles/r03_c2_tiles.txt, r03_c4_tiles.txt; B = 1, 2, 8 tables in DESIGN.md 3.2), so a sampler that never called
+// sbgm_model_autotune runs within a few per cent of a tuned one instead of on the round-1 kernels:
+//   3x3 stride 1, >= 512 tiles of 16x16 pixels x 16 channels (or the final projection): 2-D Winograd F(2x2,3x3) (conv_w2d.hip) — the
+//     persistent 32-channel kernel once there are >= 512 such tiles (two per CU), 16-channel double-buffered workgroups below;
+//   fewer tiles, or a fused input mode: the LDS-staged 1-D Winograd kernel on 16-channel slices (conv_lds.hip);
+//   3x3 stride 1 with >= 2048 pixels of >= 128 channels (the 8x8 / 4x4 maps of a full batch): 1-D Winograd (conv_wino.hip), the largest
+//     tile that still gives >= 256 workgroups, the K loop split over 4 or 8 waves;
+//   small problems of any geometry (< 1024 tiles of 32 channels x 16 pixels): that smallest wave tile, K split over the 4 waves of
+//     a workgroup and over up to 8 workgroups;
+//   everything else (strided, 1x1, the stem): wave tiles that fill ~2 waves per SIMD.
 ConvTile sbgm_model::pick_tile(const ConvGeom& g, const ConvParams& p) {
     const int OH = (p.H + 2 * g.pad - g.kh) / g.stride + 1, OW = (p.W + 2 * g.pad - g.kw) / g.stride + 1;
     ConvOpKey key{g.kh, g.kw, g.stride, g.pad, p.B, p.H, p.W, p.Cs, p.Cout, p.proj_w != nullptr, p.in_mode};
     auto it = tuned.find(key);
     if (it != tuned.end()) return it->second;
+    static const bool round1 = getenv("SBGM_STATIC_ROUND1") != nullptr;      // the round-1 table (A/B of this function)
+    static const bool lds_ok = getenv("SBGM_NO_LDS_CONV") == nullptr && !round1;
+    const bool s1 = g.kh == 3 && g.kw == 3 && g.stride == 1 && g.pad == 1 && p.in_dil <= 1;
+    const int M = p.B * OH * OW;
+    const int nsteps = sbgm_conv_nsteps(g.kh, g.kw, p.c_real == 2 ? 2 : p.Cs);
+    if (lds_ok && s1 && p.W % 16 == 0 && p.H % 2 == 0 && p.Cs % 16 == 0) {
+        const long tiles16 = (long)p.B * (p.W / 16) * ((p.H + 15) / 16) * (p.Cout / 16);
+        if (p.wp_w2d != nullptr && (tiles16 >= 512 || p.proj_w)) {
+            const ConvTile big{2, 1, 1, 2, 2, 3}, mid{1, 1, 1, 2, 2, 3};
+            if (p.Cout % 32 == 0 && tiles16 >= 1024 && sbgm_conv_w2d_bytes(big, p.in_mode) <= 160 * 1024) return big;
+            if (p.proj_w && sbgm_conv_w2d_bytes(mid, p.in_mode) <= 160 * 1024) return mid;
+            for (int lds : {2, 1}) {
+                const ConvTile small{1, 1, 1, 1, 2, lds};
+                if (!p.proj_w && sbgm_conv_w2d_bytes(small, p.in_mode) <= 160 * 1024) return small;
+            }
+        }
+        if (p.wp_wino != nullptr && !p.proj_w && (p.in_mode != 0 || tiles16 >= 256 || (tiles16 >= 128 && p.W >= 32)))
+            for (int lds : {2, 1}) {
+                const ConvTile t{1, 1, 1, 1, 1, lds};
+                if (sbgm_conv_lds_bytes(t, p.in_mode) <= 160 * 1024) return t;
+            }
+    }
     if (p.in_mode != 0) return ConvTile{p.Cout % 64 == 0 ? 4 : 2, 1, 1, 1, 1, 1};     // fused input modes: LDS-staged Winograd tiles only
-    const bool wino_ok = p.wp_wino != nullptr && g.kh == 3 && g.kw == 3 && g.stride == 1 && g.pad == 1 && p.W % 2 == 0;
-    if (wino_ok) {                                    // Winograd F(2,3): 1.5x fewer MFMAs; pick waves-per-tile to fill the chip
+    const bool wino_ok = p.wp_wino != nullptr && s1 && p.W % 2 == 0;
+    if (wino_ok && p.proj_w) return ConvTile{p.Cout / 16, 1, 1, 1, 1, 0};
+    if (wino_ok && !round1 && ((M >= 2048 && p.Cs >= 128) || (M >= 512 && p.Cs >= 512 && p.Cout >= 512))) {
+        const int ns = 3 * (p.Cs / 16);
+        const int wt[3][2] = {{4, 2}, {4, 1}, {2, 1}};
+        for (auto& t : wt) {
+            if (p.Cout % (16 * t[0])) continue;
+            const long wgs = (long)((M + 32 * t[1] - 1) / (32 * t[1])) * (p.Cout / (16 * t[0]));
+            if (wgs >= 256 || (t[0] == 2 && t[1] == 1)) {
+                int ws = t[1] == 2 ? 4 : ((p.Cs >= 512 || wgs < 512) ? 8 : 4);
+                while (ws > 1 && ns / ws < 2) ws >>= 1;
+                return ConvTile{t[0], t[1], 1, ws, 1, 0};
+            }
+        }
+    }
+    if (wino_ok && round1) {                          // Winograd F(2,3): 1.5x fewer MFMAs; pick waves-per-tile to fill the chip
         const int Mp = p.B * OH * OW / 2, ns = 3 * (p.Cs / 16);
-        if (p.proj_w) return ConvTile{p.Cout / 16, 1, 1, 1, 1, 0};
         const long tiles = (long)((Mp + 31) / 32) * (p.Cout / 32);          // (2,2) tiles: 32 channels x 64 pixels
         const int ws = tiles >= 2048 ? 1 : (tiles >= 1024 || ns < 8) ? 2 : 4;
         return ConvTile{2, 2, 1, ws, 1, 0};
     }
     if (p.proj_w) return ConvTile{p.Cout / 16, 2, 1, 1, 0, 0};
-    const int M = p.B * OH * OW;
-    const int nsteps = sbgm_conv_nsteps(g.kh, g.kw, p.c_real == 2 ? 2 : p.Cs);
+    const long t21 = (long)((M + 15) / 16) * (p.Cout / 32);
+    if (!round1 && p.Cout % 32 == 0 && t21 < 1024) {
+        const int ws = nsteps >= 8 ? 4 : nsteps >= 4 ? 2 : 1;
+        int splits = 1;
+        while (splits < 8 && t21 * splits * 2 <= 256 && nsteps / (splits * 2 * ws) >= 4) splits *= 2;
+        return ConvTile{2, 1, splits, ws, 0, 0};
+    }
     const int target = 2048;                 // ~2 waves per SIMD
     const int cand[3][2] = {{4, 4}, {4, 2}, {2, 2}};
     for (auto& c : cand) {

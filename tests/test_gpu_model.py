@@ -190,6 +190,36 @@ def test_tile_table_save_load_roundtrip(tmp_path):
         b.autotune(2, 64, 64, cache=bad)
 
 
+def test_static_plan_uses_the_current_kernels_and_agrees_with_the_tuned_plan(tmp_path):
+    """A sampler or forward call that never ran the autotuner must not fall back to the first-generation kernels: at the C2 shape
+    the static choice (engine.hip pick_tile) puts the large 3x3 layers on the 2-D Winograd kernels and the 8x8 / 4x4 maps on the
+    1-D Winograd kernel, and its output equals the tuned plan's up to the kernels' rounding."""
+    import csv
+    import ctypes as C
+    from sbgm_danra_amd import _native as N
+    _, net, _ = build_pair(1)
+    net.eval()
+    g = torch.Generator().manual_seed(3)
+    B, HW = 32, 128
+    x, c = torch.randn(B, 1, HW, HW, generator=g).cuda(), torch.randn(B, 1, HW, HW, generator=g).cuda()
+    t = (torch.rand(B, generator=g) * 0.999 + 1e-3).cuda()
+    with torch.no_grad():
+        static = net(x, t, cond_img=c)
+    eng = net._engine(None, None, c)
+    prof, o, path = N.Profile(), torch.empty_like(x), str(tmp_path / "convs.csv")
+    N.check(N.lib().sbgm_model_profile_forward(eng.h, x.data_ptr(), t.data_ptr(), None, c.data_ptr(), None, None, o.data_ptr(), B, HW, HW,
+                                               C.byref(prof), path.encode(), N.stream()))
+    rows = list(csv.DictReader(open(path)))
+    big = [r for r in rows if r["kh"] == "3" and r["stride"] == "1" and int(r["W"]) >= 32 and int(r["Cin_pad"]) >= 64]
+    small = [r for r in rows if r["kh"] == "3" and r["stride"] == "1" and int(r["W"]) <= 8]
+    assert big and all("w2d" in r["kernel"] for r in big), [r["kernel"] for r in big]
+    assert small and all("wino" in r["kernel"] for r in small), [r["kernel"] for r in small]
+    net.autotune(B, HW, HW)
+    with torch.no_grad():
+        tuned = net(x, t, cond_img=c)
+    assert maxrel(static.cpu(), tuned.cpu()) <= 2e-5
+
+
 def test_full_size_properties_b32_128():
     """BASELINE config 2 shape (B=32, 128x128, 1 condition): size-independent properties instead of an oracle run:
     samples are independent in eval mode (row i of a batched evaluation == the same row evaluated alone),
