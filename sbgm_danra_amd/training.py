@@ -161,6 +161,34 @@ class TrainingPipeline_general:
         _native.bump_generation()       # the replay moved BatchNorm running statistics / num_batches_tracked without a version bump
         return x, loss
 
+    class _LossMeter:
+        """Sum of the per-batch losses without a host synchronisation per step.  The reference reads `loss.item()` after every
+        optimizer step (training.py:410), which parks the device while the host collates the next batch; here each loss is copied
+        into a slot of a device buffer and the buffer is read back every `cap` steps and at the end — the same fp32 losses summed
+        in the same order in a Python float, so the reported epoch mean is unchanged while the loader overlaps the running step."""
+
+        def __init__(self, device, cap=64):
+            self.device, self.cap, self.buf = torch.device(device), cap, None
+            self.n, self.total = 0, 0.0
+
+        def add(self, loss):
+            if self.device.type != "cuda":
+                self.total += loss.item()
+                return
+            if self.buf is None:
+                self.buf = torch.empty(self.cap, device=loss.device)
+            self.buf[self.n].copy_(loss.detach())
+            self.n += 1
+            if self.n == self.buf.numel():
+                self.flush()
+
+        def flush(self):
+            if self.buf is not None and self.n:
+                for v in self.buf[: self.n].tolist():
+                    self.total += v
+                self.n = 0
+            return self.total
+
     def train_batches(self, dataloader, epochs=10, current_epoch=1, verbose=True, use_mixed_precision=False):
         if use_mixed_precision:
             raise NotImplementedError("fp32 only: the reference's autocast branch is commented out (training.py:325-343)")
@@ -172,7 +200,7 @@ class TrainingPipeline_general:
         fold = self._bucket is not None and hasattr(self.optimizer, "grad_scale")
         if fold:
             self.optimizer.grad_scale = 1.0 / world
-        loss_sum = 0.0
+        meter = self._LossMeter(self.device)
         use_graph = bool(self.cfg["training"].get("use_hip_graph", False)) and torch.device(self.device).type == "cuda"
         from . import train_graph
         if use_graph and train_graph._sync_world() is not None:
@@ -191,20 +219,20 @@ class TrainingPipeline_general:
             if self._bucket is not None:
                 self._bucket.all_reduce_(average=not fold)   # the exchange step of the path (its decoder part started inside backward)
             self.optimizer.step()
-            loss_sum += batch_loss.item()
+            meter.add(batch_loss)
         train_graph.set_overlap_bucket(prev_overlap)
-        avg = loss_sum / max(1, len(dataloader))
+        avg = meter.flush() / max(1, len(dataloader))
         if verbose:
             logger.info(f"→ Epoch {current_epoch}/{epochs} completed: Avg. training Loss: {avg:.4f}")
         return avg
 
     def validate_batches(self, dataloader, verbose=True):
         self.model.eval()
-        loss_sum = 0.0
+        meter = self._LossMeter(self.device)
         with torch.inference_mode():
             for samples in dataloader:
-                loss_sum += self._loss(samples, "valid")[1].item()
-        avg = loss_sum / max(1, len(dataloader))
+                meter.add(self._loss(samples, "valid")[1])
+        avg = meter.flush() / max(1, len(dataloader))
         if verbose:
             logger.info(f"→ Validation Loss: {avg:.4f}")
         return avg
