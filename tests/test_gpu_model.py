@@ -220,6 +220,25 @@ def test_static_plan_uses_the_current_kernels_and_agrees_with_the_tuned_plan(tmp
     assert maxrel(static.cpu(), tuned.cpu()) <= 2e-5
 
 
+@pytest.mark.parametrize("B,H,W", [(8, 96, 128), (40, 96, 128)])
+def test_non_square_maps_with_ragged_tile_rows(B, H, W):
+    """96 x 128 inputs put 24-row maps (one and a half 16-row tiles) on the LDS-staged kernels: at B = 8 the static plan takes the
+    row-Winograd tiles there, at B = 40 the 2-D Winograd ones.  One sample against the oracle, the batch against that sample alone."""
+    ora, net, _ = build_pair(1)
+    ora.eval(), net.eval()
+    g = torch.Generator().manual_seed(H + W + B)
+    x, c = torch.randn(B, 1, H, W, generator=g), torch.randn(B, 1, H, W, generator=g)
+    t = torch.rand(B, generator=g) * 0.999 + 1e-3
+    k = B // 2
+    with torch.no_grad():
+        full = net(x.cuda(), t.cuda(), cond_img=c.cuda())
+        solo = net(x[k:k + 1].cuda(), t[k:k + 1].cuda(), cond_img=c[k:k + 1].cuda())
+        want = ora(x[k:k + 1], t[k:k + 1], cond_img=c[k:k + 1])
+    assert torch.isfinite(full).all()
+    check_parity(solo.cpu(), want, TOL, f"non-square {H}x{W} solo")
+    assert maxrel(full[k:k + 1].cpu(), solo.cpu()) <= 2e-5
+
+
 def test_full_size_properties_b32_128():
     """BASELINE config 2 shape (B=32, 128x128, 1 condition): size-independent properties instead of an oracle run:
     samples are independent in eval mode (row i of a batched evaluation == the same row evaluated alone),
