@@ -3,6 +3,9 @@ test_gpu_backward.py):
 
   C1  64x64, B=1, C_in=1 (no conditions), Euler-Maruyama: 5 injected-noise steps vs the oracle, then 50 steps
       (determinism, hipGraph replay == eager launches bit for bit)                      reference score_sampling.py:63-127
+  C2  128x128, 1 condition, B=32, Euler-Maruyama at the configuration's full length of 1000 steps through the public sampler
+      (no tuning call): hipGraph replay == eager launches bit for bit, finite, seed-reproducible; the evaluation itself is
+      checked against the oracle at this shape in test_gpu_model.py                     reference score_sampling.py:63-127
   C3  128x128, 4 LR conditions (C_in=5), B=8: one training step — loss and EVERY parameter gradient vs a float64 evaluation of
       the oracle under shared ReLU decisions (see the test), injected (t, z), synthetic weights and the reference's training
       initialisation                                                                   reference training.py:188-201, :323-410
@@ -57,6 +60,22 @@ def test_config1_64x64_single_sample_euler_maruyama():
     assert torch.isfinite(a).all() and torch.equal(a, b) and torch.equal(a, c)
     kw["seed"] = 12
     assert not torch.equal(a, S.Euler_Maruyama_sampler(net, S.marginal_prob_std_fn, S.diffusion_coeff_fn, **kw))
+
+
+def test_config2_full_length_1000_steps_graph_equals_eager():
+    """BASELINE configs[1] end to end: 32 samples, 1000 SDE steps.  The step graph is replayed 1000 times against 1000 x 72 eager
+    launches: the two results must be the same bits (step table, in-kernel Philox counters and the workspace survive a long run), a
+    second graph run with the same seed reproduces them, another seed does not."""
+    import sbgm_danra_amd as S
+    _, net, _ = build_pair(1)
+    net.eval()
+    g = torch.Generator().manual_seed(2)
+    c = torch.randn(32, 1, 128, 128, generator=g).cuda()
+    kw = dict(batch_size=32, num_steps=1000, device="cuda", img_size=128, cond_img=c)
+    run = lambda graph, seed: S.Euler_Maruyama_sampler(net, S.marginal_prob_std_fn, S.diffusion_coeff_fn, use_graph=graph, seed=seed, **kw)  # noqa: E731
+    a, b, a2, other = run(True, 9), run(False, 9), run(True, 9), run(True, 10)
+    assert a.shape == (32, 1, 128, 128) and torch.isfinite(a).all()
+    assert torch.equal(a, b) and torch.equal(a, a2) and not torch.equal(a, other)
 
 
 def _group(name):
