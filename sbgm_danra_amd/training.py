@@ -107,7 +107,7 @@ class TrainingPipeline_general:
         return x, self.loss_fn(self.model, x, self.marginal_prob_std_fn, y=seasons, cond_img=cond, lsm_cond=lsm,
                                topo_cond=topo, sdf_cond=sdf if self.sdf_weighted_loss else None)
 
-    def _graph_step(self, samples):
+    def _graph_step(self, samples, soft=False):
         """`training.use_hip_graph: true` — loss_fn + backward of one step replayed as a hipGraph (torch.cuda.graphs over the
         C-ABI launches): the ~700 launches of a step cost one host call.  The batch is copied into static input tensors; the
         first batch of a new shape runs 2 eager warm-up steps' worth of launches (tile tuning, weight-pack plan) and captures.
@@ -128,18 +128,30 @@ class TrainingPipeline_general:
                 loss.backward()
                 return loss
             saved = {k: v.detach().clone() for k, v in self.model.state_dict().items()}      # warm-up must not train
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(2):
-                    self.optimizer.zero_grad(set_to_none=True)
-                    fwd_bwd()
-            torch.cuda.current_stream().wait_stream(side)
-            self.model.load_state_dict(saved)                                                  # BatchNorm running statistics back
-            graph = torch.cuda.CUDAGraph()
-            self.optimizer.zero_grad(set_to_none=True)
-            with torch.cuda.graph(graph):
-                loss = fwd_bwd()
+            try:
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(2):
+                        self.optimizer.zero_grad(set_to_none=True)
+                        fwd_bwd()
+                torch.cuda.current_stream().wait_stream(side)
+                self.model.load_state_dict(saved)                                              # BatchNorm running statistics back
+                graph = torch.cuda.CUDAGraph()
+                self.optimizer.zero_grad(set_to_none=True)
+                with torch.cuda.graph(graph):
+                    loss = fwd_bwd()
+            except Exception as e:                                                             # noqa: BLE001
+                if not soft:
+                    raise
+                # `auto` mode: something in this step cannot be captured (a host synchronisation inside a user-supplied loss / model
+                # hook, ...).  Put the model back as it was and let the caller run this and every later step eagerly.
+                torch.cuda.synchronize()
+                self.model.load_state_dict(saved)
+                self.optimizer.zero_grad(set_to_none=True)
+                self._graph_failed = True
+                logger.warning(f"training.use_hip_graph=auto: the step could not be captured ({type(e).__name__}: {e}); continuing with eager steps")
+                return None
             # each capture leaves ITS gradient tensors in .grad (graph-pool memory, or the model's arena): keep them with the
             # graph, so that replaying an older graph after a newer capture hands the optimizer the tensors that replay wrote
             params = [p for p in self.model.parameters() if p.grad is not None]
@@ -201,16 +213,28 @@ class TrainingPipeline_general:
         if fold:
             self.optimizer.grad_scale = 1.0 / world
         meter = self._LossMeter(self.device)
-        use_graph = bool(self.cfg["training"].get("use_hip_graph", False)) and torch.device(self.device).type == "cuda"
         from . import train_graph
+        # training.use_hip_graph: true / false / auto (default, also when the key is absent as in the reference's YAML files): auto
+        # captures the step on a ROCm device unless something known not to be capturable is switched on (SyncBatchNorm collectives,
+        # the model's host-side debug statistic), and falls back to eager steps if the capture itself fails
+        want = self.cfg["training"].get("use_hip_graph", "auto")
+        auto = isinstance(want, str) and want.strip().lower() == "auto"
+        on_gpu = torch.device(self.device).type == "cuda"
+        if auto:
+            use_graph = (on_gpu and not getattr(self, "_graph_failed", False) and train_graph._sync_world() is None
+                         and not getattr(self.model, "debug_pre_sigma_div", False))
+        else:
+            use_graph = (want if isinstance(want, bool) else str(want).strip().lower() in ("1", "true", "yes", "on")) and on_gpu
         if use_graph and train_graph._sync_world() is not None:
             raise ValueError("training.sync_batchnorm needs host-driven collectives between kernel halves and cannot run inside a captured "
                              "step: set training.use_hip_graph: false (or sync_batchnorm: false)")
         prev_overlap = train_graph.set_overlap_bucket(self._bucket if not use_graph else None)
         for idx, samples in enumerate(dataloader):
-            if use_graph:
-                x, batch_loss = self._graph_step(samples)
+            step = self._graph_step(samples, soft=auto) if use_graph else None
+            if step is not None:
+                x, batch_loss = step
             else:
+                use_graph = False                           # (auto mode: a failed capture switches the rest of the run to eager steps)
                 self.optimizer.zero_grad()
                 x, batch_loss = self._loss(samples)
                 batch_loss.backward()

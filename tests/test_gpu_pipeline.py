@@ -204,6 +204,49 @@ def test_training_step_as_hip_graph(cfg_path):
                if not k.startswith("decoder.final_layer.time_"))
 
 
+def test_hip_graph_is_the_default_and_falls_back_when_a_step_cannot_be_captured(cfg_path):
+    """training.use_hip_graph defaults to `auto` (the reference's YAML files do not have the key): the step is captured without being
+    asked for; a loss function with a host synchronisation inside (not capturable) makes the pipeline fall back to eager steps —
+    with the model as it was before the attempt — instead of failing."""
+    from sbgm.score_unet import diffusion_coeff_fn, loss_fn, marginal_prob_std_fn
+    from sbgm.training import TrainingPipeline_general
+    from sbgm.training_utils import get_model, get_optimizer
+    from sbgm.utils import load_config
+    from sbgm_danra_amd.synthetic_data import synthetic_loader
+    cfg = load_config(cfg_path)
+    del cfg["training"]["use_hip_graph"]
+    cfg.monitoring.extreme_prcp.enabled = False
+    torch.manual_seed(0)
+    model, _, _ = get_model(cfg)
+    pipe = TrainingPipeline_general(model, loss_fn, marginal_prob_std_fn, diffusion_coeff_fn, get_optimizer(cfg, model),
+                                    torch.device("cuda"), None, cfg)
+    dl = synthetic_loader(cfg, 2, n_items=4)
+    a = pipe.train_batches(dl, epochs=1, current_epoch=1, verbose=False)
+    assert np.isfinite(a) and len(pipe._graphs) == 1 and not getattr(pipe, "_graph_failed", False)
+
+    def syncing_loss(model_, x, mps, **kw):
+        out = loss_fn(model_, x, mps, **kw)
+        float(out.detach().sum())                       # a host read inside the step: illegal under stream capture
+        return out
+    torch.manual_seed(0)
+    model2, _, _ = get_model(cfg)
+    pipe2 = TrainingPipeline_general(model2, syncing_loss, marginal_prob_std_fn, diffusion_coeff_fn, get_optimizer(cfg, model2),
+                                     torch.device("cuda"), None, cfg)
+    before = model2.encoder.conv2.weight.detach().clone()
+    b = pipe2.train_batches(dl, epochs=1, current_epoch=1, verbose=False)
+    assert np.isfinite(b) and pipe2._graph_failed and not getattr(pipe2, "_graphs", {})
+    assert int(model2.encoder.bn1.num_batches_tracked) == 2 and not torch.equal(before, model2.encoder.conv2.weight)
+    c = pipe2.train_batches(dl, epochs=2, current_epoch=2, verbose=False)          # stays eager, keeps training
+    assert np.isfinite(c) and int(model2.encoder.bn1.num_batches_tracked) == 4
+    # an explicit `true` does not hide the problem
+    cfg.training.use_hip_graph = True
+    pipe3 = TrainingPipeline_general(model2, syncing_loss, marginal_prob_std_fn, diffusion_coeff_fn, get_optimizer(cfg, model2),
+                                     torch.device("cuda"), None, cfg)
+    with pytest.raises(Exception):
+        pipe3.train_batches(dl, epochs=1, current_epoch=1, verbose=False)
+    torch.cuda.synchronize()
+
+
 def _graph_pipe(cfg_path, **training_overrides):
     from sbgm.score_unet import diffusion_coeff_fn, loss_fn, marginal_prob_std_fn
     from sbgm.training import TrainingPipeline_general
