@@ -389,6 +389,11 @@ int sbgm_layernorm_bwd(const float* x, const float* dy, const float* gamma, floa
 int sbgm_fill_zero(void* p, int64_t bytes, void* stream);
 int sbgm_mha_core_bwd(const float* qkv, const float* dout, float* dqkv, int B, int S, int C, int heads, void* stream);
 int sbgm_upsample2x_bwd(const float* dy, float* dx, int B, int H, int W, int C, void* stream);
+/* nn.Upsample(scale_factor = scale, mode="bilinear", align_corners=False) over NHWC for any integer scale in 1..16 — DecoderBlock's
+ * `upsample_scale` argument (score_unet.py:420, :467; the Decoder only ever passes 2, which has the kernels above).  x [B,H,W,C] ->
+ * y [B,scale*H,scale*W,C]; _bwd: dy [B,scale*H,scale*W,C] -> dx [B,H,W,C] (a gather: no atomics, no zeroing needed). */
+int sbgm_upsample_bilinear_fwd(const float* x, float* y, int B, int H, int W, int C, int scale, void* stream);
+int sbgm_upsample_bilinear_bwd(const float* dy, float* dx, int B, int H, int W, int C, int scale, void* stream);
 int sbgm_conv3x3_cout1_bwd(const float* dout, const float* a, const float* w_tap_c, const float* t, float sigma, float* da,
                            float* dw_tap_c, float* dbias, int B, int H, int W, int C, void* stream);
 int sbgm_time_proj_bwd(const float* dout, const float* weight, const float* semb, const float* emb_raw, float* dW,

@@ -143,6 +143,8 @@ SIGNATURES = {
     "sbgm_fill_zero": (_i, [_vp, _i64, _vp]),
     "sbgm_mha_core_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "sbgm_upsample2x_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "sbgm_upsample_bilinear_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "sbgm_upsample_bilinear_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sbgm_conv3x3_cout1_bwd": (_i, [_vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "sbgm_time_proj_bwd": (_i, [_vp] * 7 + [_i, _i, _i, _vp]),
     "sbgm_time_proj_multi_bwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

@@ -296,6 +296,12 @@ int sbgm_fill_zero(void* p, int64_t bytes, void* stream) {
 int sbgm_mha_core_bwd(const float* qkv, const float* dout, float* dqkv, int B, int S, int C, int heads, void* stream) {
     return sbgm_launch_mha_core_bwd(qkv, dout, dqkv, B, S, C, heads, ST);
 }
+int sbgm_upsample_bilinear_fwd(const float* x, float* y, int B, int H, int W, int C, int scale, void* stream) {
+    return sbgm_launch_upsample_bilinear(x, y, B, H, W, C, scale, 0, ST);
+}
+int sbgm_upsample_bilinear_bwd(const float* dy, float* dx, int B, int H, int W, int C, int scale, void* stream) {
+    return sbgm_launch_upsample_bilinear(dy, dx, B, H, W, C, scale, 1, ST);
+}
 int sbgm_upsample2x_bwd(const float* dy, float* dx, int B, int H, int W, int C, void* stream) {
     return sbgm_launch_upsample2x_bwd(dy, dx, B, H, W, C, ST);
 }

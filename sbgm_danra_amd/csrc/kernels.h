@@ -99,6 +99,8 @@ int sbgm_launch_pack_input(const PackSrc& src, float* dst_nhwc, int B, int H, in
 int sbgm_launch_nhwc_to_nchw(const float* src, float* dst, int B, int H, int W, int C, hipStream_t st);
 int sbgm_launch_nchw_to_nhwc(const float* src, float* dst, int B, int H, int W, int C, hipStream_t st);
 int sbgm_launch_upsample2x(const float* x, float* y, int B, int H, int W, int C, hipStream_t st);
+// nn.Upsample(scale_factor = scale, bilinear, align_corners=False), integer scale 1..16; backward != 0: x = dy (upsampled size), y = dx
+int sbgm_launch_upsample_bilinear(const float* x, float* y, int B, int H, int W, int C, int scale, int backward, hipStream_t st);
 // [B][H][W][4C] (phase-major channels) <-> [B][2H][2W][C]; to_space = 1: depth -> space
 int sbgm_launch_depth_space2(const float* in, float* out, int B, int H, int W, int C, int to_space, hipStream_t st);
 int sbgm_launch_tconv_weight(const float* w_cin_cout_2_2, float* oihw_4cout_cin, int Cin, int Cout, hipStream_t st);

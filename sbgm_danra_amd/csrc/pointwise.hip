@@ -93,6 +93,70 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict
     }
 }
 
+// ---- nn.Upsample(scale_factor = s, bilinear, align_corners=False) for any integer s >= 1: the DecoderBlock signature's
+// `upsample_scale` (reference score_unet.py:420, :467); the Decoder itself only ever uses 2 (kernel above, and fused into the
+// consumer convolution's load path on the sampling side).  source = max(0, (o + 0.5) / s - 0.5), as ATen's
+// area_pixel_compute_source_index with the given scale factor.
+__device__ __forceinline__ void bilinear_src(int o, float rs, int n, int& i0, int& i1, float& l) {
+    const float sp = fmaxf(0.f, ((float)o + 0.5f) * rs - 0.5f);
+    i0 = min((int)sp, n - 1);
+    i1 = min(i0 + 1, n - 1);
+    l = sp - (float)i0;
+}
+__global__ __launch_bounds__(256) void upsample_bilinear_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int H, int W,
+                                                                int C, int s, float rs) {
+    const int cq = C >> 2, OH = s * H, OW = s * W;
+    const size_t total = (size_t)B * OH * OW * cq;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % cq);
+        size_t r = i / cq;
+        const int ox = (int)(r % OW); r /= OW;
+        const int oy = (int)(r % OH);
+        const int b = (int)(r / OH);
+        int y0, y1, x0, x1;
+        float ly, lx;
+        bilinear_src(oy, rs, H, y0, y1, ly);
+        bilinear_src(ox, rs, W, x0, x1, lx);
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        const float* base = x + (size_t)b * H * W * C + q * 4;
+        const f32x4 v00 = *reinterpret_cast<const f32x4*>(base + ((size_t)y0 * W + x0) * C);
+        const f32x4 v01 = *reinterpret_cast<const f32x4*>(base + ((size_t)y0 * W + x1) * C);
+        const f32x4 v10 = *reinterpret_cast<const f32x4*>(base + ((size_t)y1 * W + x0) * C);
+        const f32x4 v11 = *reinterpret_cast<const f32x4*>(base + ((size_t)y1 * W + x1) * C);
+        *reinterpret_cast<f32x4*>(y + i * 4) = hy * (hx * v00 + lx * v01) + ly * (hx * v10 + lx * v11);
+    }
+}
+// backward as a gather: an input pixel collects from the output rows / columns whose two taps include it (no atomics, fixed order)
+__global__ __launch_bounds__(256) void upsample_bilinear_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int B, int H,
+                                                                    int W, int C, int s, float rs) {
+    const int cq = C >> 2, OH = s * H, OW = s * W;
+    const size_t total = (size_t)B * H * W * cq;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const int q = (int)(i % cq);
+        size_t r = i / cq;
+        const int ix = (int)(r % W); r /= W;
+        const int iy = (int)(r % H);
+        const int b = (int)(r / H);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* base = dy + (size_t)b * OH * OW * C + q * 4;
+        for (int oy = max(0, s * (iy - 1)); oy < min(OH, s * (iy + 2)); ++oy) {
+            int y0, y1;
+            float ly;
+            bilinear_src(oy, rs, H, y0, y1, ly);
+            const float wy = (y0 == iy ? 1.f - ly : 0.f) + (y1 == iy ? ly : 0.f);
+            if (wy == 0.f) continue;
+            for (int ox = max(0, s * (ix - 1)); ox < min(OW, s * (ix + 2)); ++ox) {
+                int x0, x1;
+                float lx;
+                bilinear_src(ox, rs, W, x0, x1, lx);
+                const float wx = (x0 == ix ? 1.f - lx : 0.f) + (x1 == ix ? lx : 0.f);
+                if (wx != 0.f) acc += (wy * wx) * *reinterpret_cast<const f32x4*>(base + ((size_t)oy * OW + ox) * C);
+            }
+        }
+        *reinterpret_cast<f32x4*>(dx + i * 4) = acc;
+    }
+}
+
 // ---- K10 (eval): fold BatchNorm2d running statistics into a per-channel scale / bias ------------------
 __global__ void bn_fold_kernel(const float* g, const float* be, const float* mu, const float* var, float eps,
                                float* scale, float* bias, int C) {
@@ -340,6 +404,18 @@ int sbgm_launch_nhwc_to_nchw(const float* src, float* dst, int B, int H, int W, 
 int sbgm_launch_upsample2x(const float* x, float* y, int B, int H, int W, int C, hipStream_t st) {
     SBGM_CHECK(C % 4 == 0, "upsample2x: C=%d must be a multiple of 4", C);
     hipLaunchKernelGGL(upsample2x_kernel, dim3(stream_blocks((size_t)B * H * W * C)), dim3(256), 0, st, x, y, B, H, W, C);
+    SBGM_LAUNCH_CHECK();
+    return 0;
+}
+
+int sbgm_launch_upsample_bilinear(const float* x, float* y, int B, int H, int W, int C, int scale, int backward, hipStream_t st) {
+    SBGM_CHECK(C % 4 == 0 && scale >= 1 && scale <= 16, "upsample_bilinear: C=%d must be a multiple of 4, scale=%d in 1..16", C, scale);
+    SBGM_CHECK((size_t)B * H * W * scale * scale * C < ((size_t)1 << 40), "upsample_bilinear: tensor too large");
+    const float rs = (float)(1.0 / (double)scale);
+    if (backward)      // x = dy [B][sH][sW][C], y = dx [B][H][W][C]
+        hipLaunchKernelGGL(upsample_bilinear_bwd_kernel, dim3(stream_blocks((size_t)B * H * W * C)), dim3(256), 0, st, x, y, B, H, W, C, scale, rs);
+    else
+        hipLaunchKernelGGL(upsample_bilinear_kernel, dim3(stream_blocks((size_t)B * H * W * scale * scale * C)), dim3(256), 0, st, x, y, B, H, W, C, scale, rs);
     SBGM_LAUNCH_CHECK();
     return 0;
 }

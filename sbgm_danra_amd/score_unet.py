@@ -154,8 +154,10 @@ class DecoderBlock(_NativeOnly):
         self.upsample_scale, self.time_embedding = upsample_scale, time_embedding
         self.compute_attn, self.n_heads = compute_attn, n_heads
         self.use_resize_conv, self.norm_kind, self.gn_groups = use_resize_conv, norm, gn_groups
-        if upsample_scale != 2:
-            raise NotImplementedError("only the reference's x2 decoder upsampling is implemented")
+        if int(upsample_scale) != upsample_scale or not 1 <= upsample_scale <= 16:
+            raise NotImplementedError("upsample_scale must be an integer in 1..16")
+        if upsample_scale != 2 and not use_resize_conv:
+            raise NotImplementedError("the ConvTranspose2d ablation path is implemented for the reference's x2 upsampling only")
         if use_resize_conv:
             self.upsample = nn.Upsample(scale_factor=upsample_scale, mode="bilinear", align_corners=False)
             self.conv_up = nn.Conv2d(input_channels, input_channels, kernel_size=3, padding=1, bias=True)
@@ -236,6 +238,10 @@ class _Engine:
         act = _ACT_CODE.get(dec.activation)
         if act is None:
             raise NotImplementedError(f"decoder activation {dec.activation} not implemented natively")
+        odd = [i for i, b in enumerate(list(dec.residual_layers) + [dec.final_layer]) if getattr(b, "upsample_scale", 2) != 2]
+        if odd:
+            raise NotImplementedError(f"the whole-network engine runs the reference Decoder's x2 blocks; blocks {odd} have another "
+                                      f"upsample_scale (such blocks run when called on their own)")
         cfg = N.ModelConfig(C.sizeof(N.ModelConfig), n_lsm, n_topo, n_cond, enc.time_embedding, (C.c_int * 4)(*enc.block_layers), enc.n_heads,
                             enc.num_classes or 0, dec.last_fmap_channels,
                             N.NORM_GROUP if dec.norm == "group" else N.NORM_INSTANCE, dec.gn_groups, act,

@@ -810,21 +810,28 @@ class MHACoreFn(torch.autograd.Function):
 
 
 class UpsampleFn(torch.autograd.Function):
+    """nn.Upsample(scale_factor=scale, bilinear, align_corners=False) over NHWC; scale 2 (every block of the Decoder) has its own kernels"""
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, scale=2):
         B, H, W, Cc = x.shape
-        y = torch.empty(B, 2 * H, 2 * W, Cc, device=x.device)
-        N.check(_L().sbgm_upsample2x_fwd(x.data_ptr(), y.data_ptr(), B, H, W, Cc, _st()))
-        ctx.dims = (B, H, W, Cc)
+        y = torch.empty(B, scale * H, scale * W, Cc, device=x.device)
+        if scale == 2:
+            N.check(_L().sbgm_upsample2x_fwd(x.data_ptr(), y.data_ptr(), B, H, W, Cc, _st()))
+        else:
+            N.check(_L().sbgm_upsample_bilinear_fwd(x.data_ptr(), y.data_ptr(), B, H, W, Cc, scale, _st()))
+        ctx.dims = (B, H, W, Cc, scale)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        B, H, W, Cc = ctx.dims
+        B, H, W, Cc, scale = ctx.dims
         dy = dy.contiguous()
         dx = torch.empty(B, H, W, Cc, device=dy.device)
-        N.check(_L().sbgm_upsample2x_bwd(dy.data_ptr(), dx.data_ptr(), B, H, W, Cc, _st()))
-        return dx
+        if scale == 2:
+            N.check(_L().sbgm_upsample2x_bwd(dy.data_ptr(), dx.data_ptr(), B, H, W, Cc, _st()))
+        else:
+            N.check(_L().sbgm_upsample_bilinear_bwd(dy.data_ptr(), dx.data_ptr(), B, H, W, Cc, scale, _st()))
+        return dx, None
 
 
 class DepthToSpaceFn(torch.autograd.Function):
@@ -1177,7 +1184,7 @@ def encoder_forward(enc, x, t, y, cond, lsm, topo, skip_slots=None):
 
 def _upsampled(blk, h):           # (A) of DecoderBlock: resize-conv (default) or the ConvTranspose2d ablation path
     if blk.use_resize_conv:
-        return ConvFn.apply(UpsampleFn.apply(h), blk.conv_up.weight, blk.conv_up.bias, None, None, 1, 1)
+        return ConvFn.apply(UpsampleFn.apply(h, int(blk.upsample_scale)), blk.conv_up.weight, blk.conv_up.bias, None, None, 1, 1)
     return conv_transpose2x(h, blk.transpose)
 
 
@@ -1191,7 +1198,11 @@ def decoder_block_forward(blk, cur, skip, t, tbd=None, sslot=None):
     act = _ACT.get(type(blk.activation).__name__)
     if act is None:
         raise NotImplementedError(f"decoder activation {type(blk.activation).__name__} not implemented natively")
-    a = GroupNormFn.apply(_upsampled(blk, cur), *g(blk.norm1), None, None, N.NONE, G1, 1e-5)
+    up = _upsampled(blk, cur)
+    if skip is not None:                                         # reference :596-597 (every block asserts this, also inside Decoder.forward)
+        want = (up.shape[0], up.shape[1], up.shape[2], blk.output_channels)
+        assert tuple(skip.shape) == want, f"prev_fmap shape {tuple(skip.shape)} (NHWC) must match output shape {want}"
+    a = GroupNormFn.apply(up, *g(blk.norm1), None, None, N.NONE, G1, 1e-5)
     c2 = ConvFn.apply(a, blk.conv.weight, blk.conv.bias, None, None, 1, 1)
     if tbd is None and t is not None:
         tbd = _tproj(t, None, None, blk.sinusoidal_embedding, blk.time_projection_layer)

@@ -5,6 +5,7 @@ import os
 
 import pytest
 import torch
+import torch.nn as nn
 
 pytestmark = pytest.mark.gpu
 
@@ -435,6 +436,44 @@ def test_standalone_submodule_calls_match_the_oracle(mode):
                 go, = torch.autograd.grad(yo.square().mean(), xo)
                 gn, = torch.autograd.grad(yn.square().mean(), xn)
                 assert maxrel(gn.cpu(), go) < 1e-4, i
+
+
+@pytest.mark.parametrize("scale,with_skip", [(4, True), (1, False), (3, True)])
+def test_decoder_block_with_another_upsample_scale(scale, with_skip):
+    """DecoderBlock(upsample_scale=s) (reference score_unet.py:420, :467: nn.Upsample(scale_factor=s, bilinear)) called on its own,
+    forward and gradients against the oracle's block with the same weights.  The whole-network engine refuses such a block."""
+    import sbgm_danra_amd as S
+    from oracle import torch_ref as O
+    torch.manual_seed(scale)
+    bo = O.DecoderBlock(128, 64, 128, upsample_scale=scale, activation=nn.SiLU, compute_attn=False, norm="group", gn_groups=8)
+    bn = S.DecoderBlock(128, 64, 128, upsample_scale=scale, activation=nn.SiLU, compute_attn=False, norm="group", gn_groups=8).cuda()
+    bn.load_state_dict(bo.state_dict())
+    g = torch.Generator().manual_seed(7)
+    B, h = 3, 6
+    x, t = torch.randn(B, 128, h, h + 2, generator=g), torch.rand(B, generator=g) * 0.9 + 0.05
+    skip = torch.randn(B, 64, scale * h, scale * (h + 2), generator=g) if with_skip else None
+    xo, xn = x.clone().requires_grad_(True), x.cuda().requires_grad_(True)
+    yo = bo(xo, skip, t)
+    yn = bn(xn, None if skip is None else skip.cuda(), t.cuda())
+    assert yn.shape == yo.shape == (B, 64, scale * h, scale * (h + 2))
+    assert maxrel(yn.detach().cpu(), yo.detach()) <= TOL
+    yo.square().mean().backward()
+    yn.square().mean().backward()
+    assert maxrel(xn.grad.cpu(), xo.grad) < 1e-4
+    po, pn = dict(bo.named_parameters()), dict(bn.named_parameters())
+    for k in ("conv_up.weight", "conv.weight", "norm1.weight", "time_projection_layer.1.weight"):
+        assert maxrel(pn[k].grad.cpu(), po[k].grad) < 1e-4, k
+    with pytest.raises(NotImplementedError):
+        S.DecoderBlock(64, 32, 128, upsample_scale=4, use_resize_conv=False)
+    if scale == 4:
+        _, net, _ = build_pair(1)
+        net.decoder.residual_layers[3] = S.DecoderBlock(64, 64, 256, upsample_scale=4, activation=nn.SiLU, compute_attn=False,
+                                                        norm="group", gn_groups=8).cuda()
+        args = (torch.zeros(1, 1, 64, 64).cuda(), torch.tensor([0.5]).cuda())
+        with pytest.raises(NotImplementedError), torch.no_grad():       # the whole-network engine (sampling path) runs x2 blocks only
+            net.eval()(*args, cond_img=torch.zeros(1, 1, 64, 64).cuda())
+        with pytest.raises(AssertionError):                             # the autograd path runs the block; its skip no longer fits (:596-597)
+            net.eval()(*args, cond_img=torch.zeros(1, 1, 64, 64).cuda())
 
 
 def test_cached_step_graph_is_reused_across_runs_with_other_seeds_and_lengths():

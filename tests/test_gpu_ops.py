@@ -400,6 +400,27 @@ def test_attention_token_kernels(M, C_):
         N.check(lib().sbgm_attn_qkv_fwd(xd.data_ptr(), *[t.data_ptr() for t in head], qkv.data_ptr(), M, 96, 1e-5, N.stream()))
 
 
+@pytest.mark.parametrize("scale", [1, 3, 4, 8])
+def test_bilinear_upsample_integer_scales(scale):
+    """sbgm_upsample_bilinear_fwd / _bwd == nn.Upsample(scale_factor=s, mode="bilinear", align_corners=False) and its autograd"""
+    F = torch.nn.functional
+    B, H, W, C_ = 2, 5, 7, 8
+    x = rnd(B, C_, H, W, seed=scale).requires_grad_(True)
+    y = F.interpolate(x, scale_factor=float(scale), mode="bilinear", align_corners=False)
+    go = rnd(B, C_, scale * H, scale * W, seed=scale + 10)
+    y.backward(go)
+    xd = x.detach().permute(0, 2, 3, 1).contiguous().to(DEV)
+    yd = torch.full((B, scale * H, scale * W, C_), float("nan"), device=DEV)
+    N.check(lib().sbgm_upsample_bilinear_fwd(xd.data_ptr(), yd.data_ptr(), B, H, W, C_, scale, N.stream()))
+    assert relerr(yd.permute(0, 3, 1, 2).cpu(), y.detach()) < 1e-6
+    gd = go.permute(0, 2, 3, 1).contiguous().to(DEV)
+    dxd = torch.full((B, H, W, C_), float("nan"), device=DEV)
+    N.check(lib().sbgm_upsample_bilinear_bwd(gd.data_ptr(), dxd.data_ptr(), B, H, W, C_, scale, N.stream()))
+    assert relerr(dxd.permute(0, 3, 1, 2).cpu(), x.grad) < 1e-6
+    with pytest.raises(N.NativeError):
+        N.check(lib().sbgm_upsample_bilinear_fwd(xd.data_ptr(), yd.data_ptr(), B, H, W, C_, 0, N.stream()))
+
+
 def test_mha_online_softmax_rescale_branch():
     """spike late keys so the running max jumps in a later key block (guide rule: force the rescale path)"""
     B, S, C_, heads = 1, 64, 64, 2
