@@ -300,6 +300,16 @@ int sbgm_batchnorm_train_apply(const float* x, float* y, const float* gamma, con
                                float eps, float momentum, void* stats_ws, double n_total, float* mean_rstd_out, void* stream);
 /* Core of nn.MultiheadAttention between in_proj and out_proj: qkv [B,S,3C] -> [B,S,C].  score_unet.py:142 */
 int sbgm_mha_core_fwd(const float* qkv, float* out, int B, int S, int C, int heads, void* stream);
+/* The same core with TRAIN-MODE DROPOUT on the softmax probabilities — nn.MultiheadAttention(dropout = p), the `dropout` argument of
+ * ImageSelfAttention (score_unet.py:118-127): out = (softmax(q k^T / sqrt(d)) o D) v with D_ij = keep_ij / (1 - p), keep_ij drawn from a
+ * Philox stream keyed by (seed, offset, ((b heads + h) S + i) S + j).  _bwd needs the same (p, seed, offset) and the forward's qkv; dqkv
+ * [B,S,3C] is accumulated with atomics (zeroed by the call unless sbgm_set_scratch_prezeroed(1)).  sbgm_mha_dropout_mask writes D
+ * [B,heads,S,S] (how the tests compare against an explicit-mask evaluation).  0 <= p < 1; 32 * S bytes of LDS per workgroup. */
+int sbgm_mha_core_dropout_fwd(const float* qkv, float* out, int B, int S, int C, int heads, float p, uint64_t seed, uint64_t offset,
+                              void* stream);
+int sbgm_mha_core_dropout_bwd(const float* qkv, const float* dout, float* dqkv, int B, int S, int C, int heads, float p, uint64_t seed,
+                              uint64_t offset, void* stream);
+int sbgm_mha_dropout_mask(float* mask, int B, int S, int heads, float p, uint64_t seed, uint64_t offset, void* stream);
 /* The per-token halves of ImageSelfAttention (score_unet.py:141-145) as single launches over token tiles, C in {64,128,256,512}:
  *   sbgm_attn_qkv_fwd : qkv[M][3C] = LayerNorm(x; ln_gamma, ln_beta) . in_proj_weight^T + in_proj_bias          (self.ln1 + mha in_proj)
  *   sbgm_attn_tail_fwd: h = x + att . out_proj^T + b_out;  out = h + ff[2](GELU(ff[0](LayerNorm(h))))           (:142-145)

@@ -126,6 +126,9 @@ SIGNATURES = {
     "sbgm_wgrad_flush_pending": (_i, []),
     "sbgm_wgrad_discard": (_i, []),
     "sbgm_attn_qkv_fwd": (_i, [_vp] * 6 + [_i, _i, _f, _vp]),
+    "sbgm_mha_core_dropout_fwd": (_i, [_vp, _vp, _i, _i, _i, _i, _f, _u64, _u64, _vp]),
+    "sbgm_mha_core_dropout_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _f, _u64, _u64, _vp]),
+    "sbgm_mha_dropout_mask": (_i, [_vp, _i, _i, _i, _f, _u64, _u64, _vp]),
     "sbgm_attn_tail_fwd": (_i, [_vp] * 11 + [_i, _i, _f, _vp]),
     "sbgm_time_proj_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
     "sbgm_cout1_pack_weight": (_i, [_vp, _vp, _i, _vp]),

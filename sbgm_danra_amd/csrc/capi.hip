@@ -182,6 +182,16 @@ int sbgm_batchnorm_train_fwd(const float* x, float* y, const float* gamma, const
 int sbgm_mha_core_fwd(const float* qkv, float* out, int B, int S, int C, int heads, void* stream) {
     return sbgm_launch_mha_core(qkv, out, B, S, C, heads, ST);
 }
+int sbgm_mha_core_dropout_fwd(const float* qkv, float* out, int B, int S, int C, int heads, float p, uint64_t seed, uint64_t offset, void* stream) {
+    return sbgm_launch_mha_core_dropout(qkv, nullptr, out, B, S, C, heads, p, seed, offset, 0, ST);
+}
+int sbgm_mha_core_dropout_bwd(const float* qkv, const float* dout, float* dqkv, int B, int S, int C, int heads, float p, uint64_t seed,
+                              uint64_t offset, void* stream) {
+    return sbgm_launch_mha_core_dropout(qkv, dout, dqkv, B, S, C, heads, p, seed, offset, 1, ST);
+}
+int sbgm_mha_dropout_mask(float* mask, int B, int S, int heads, float p, uint64_t seed, uint64_t offset, void* stream) {
+    return sbgm_launch_mha_dropout_mask(mask, B, S, heads, p, seed, offset, ST);
+}
 int sbgm_attn_qkv_fwd(const float* x, const float* ln_gamma, const float* ln_beta, const float* w_in_packed, const float* b_in,
                       float* qkv, int M, int C, float eps, void* stream) {
     return sbgm_launch_attn_in(x, ln_gamma, ln_beta, w_in_packed, b_in, qkv, M, C, eps, ST);

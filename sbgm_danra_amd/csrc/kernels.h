@@ -176,6 +176,12 @@ int sbgm_launch_batchnorm_bwd_apply(const float* x, const float* dy, const float
 int sbgm_launch_mha_core(const float* qkv, float* out, int B, int S, int C, int heads, hipStream_t st);
 // attn_tokens.hip: the per-token halves of an attention block, one launch each (C in {64, 128, 256, 512})
 int sbgm_attn_tokens_supported(int C);
+// ---- attention_dropout.hip: the attention core with train-mode dropout on the softmax probabilities (Philox mask keyed by seed / offset)
+// forward: out_or_dqkv = out [B,S,C], dout unused;  backward != 0: out_or_dqkv = dqkv [B,S,3C] (zeroed unless sbgm_scratch_prezeroed)
+int sbgm_launch_mha_core_dropout(const float* qkv, const float* dout, float* out_or_dqkv, int B, int S, int C, int heads, float p,
+                                 unsigned long long seed, unsigned long long offset, int backward, hipStream_t st);
+int sbgm_launch_mha_dropout_mask(float* mask, int B, int S, int heads, float p, unsigned long long seed, unsigned long long offset,
+                                 hipStream_t st);
 int sbgm_launch_attn_in(const float* x, const float* ln_g, const float* ln_b, const float* w_packed, const float* bias, float* qkv,
                         int M, int C, float eps, hipStream_t st);
 int sbgm_launch_attn_out(const float* att, const float* x, const float* wo, const float* bo, const float* ln_g, const float* ln_b,

@@ -60,9 +60,9 @@ class ImageSelfAttention(_NativeOnly):
         super().__init__()
         if input_channels % n_heads != 0:
             raise ValueError(f"Number of input channels ({input_channels}) must be divisible by number of heads ({n_heads}).")
-        # dropout > 0 is accepted as in the reference's signature (:118-127): it is the identity in eval mode, which is all the sampling
-        # path needs.  A TRAIN-mode evaluation with p > 0 would have to drop attention weights inside the MHA core; that is refused at
-        # call time (train_graph._attention / ScoreNet.forward) — the reference's own DecoderBlock / Encoder never pass a non-zero p.
+        # dropout > 0 as in the reference's signature (:118-127): the identity in eval mode (all the sampling path needs); in train mode
+        # the autograd path drops softmax probabilities inside the attention core (csrc/attention_dropout.hip, Philox mask seeded from
+        # torch's generator).  The reference's own DecoderBlock / Encoder never pass a non-zero p.
         self.input_channels, self.n_heads, self.dropout = input_channels, n_heads, float(dropout)
         self.mha = nn.MultiheadAttention(embed_dim=input_channels, num_heads=n_heads, dropout=dropout, batch_first=True)
         self.ln1 = nn.LayerNorm(input_channels)
@@ -388,7 +388,8 @@ class ScoreNet(nn.Module):
             fm_ptrs = (C.c_void_p * 5)(*[f.data_ptr() for f in _fmaps])
         train = self.training
         if train and any(isinstance(m, ImageSelfAttention) and m.dropout > 0 and m.training for m in self.modules()):
-            raise NotImplementedError("train-mode attention dropout (p > 0) is not implemented natively")
+            raise NotImplementedError("train-mode attention dropout (p > 0) runs on the autograd path (grad enabled); the whole-network "
+                                      "engine behind a no-grad train-mode evaluation / sampler has no dropout")
         N.check(eng.lib.sbgm_model_forward(eng.h, x.data_ptr(), t.data_ptr(), N.ptr(y), N.ptr(cond_img), N.ptr(lsm_cond),
                                            N.ptr(topo_cond), out.data_ptr(), fm_ptrs, B, H, W, int(train), N.stream()))
         if train:

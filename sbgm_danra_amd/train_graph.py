@@ -809,6 +809,29 @@ class MHACoreFn(torch.autograd.Function):
         return dqkv, None, None, None, None
 
 
+class MHACoreDropoutFn(torch.autograd.Function):
+    """the attention core with train-mode dropout on the softmax probabilities (nn.MultiheadAttention(dropout=p)): the mask is a Philox
+    stream keyed by `seed`, regenerated in the backward pass (csrc/attention_dropout.hip)"""
+    @staticmethod
+    def forward(ctx, qkv, B, S, Cc, heads, p, seed):
+        out = torch.empty(B * S, Cc, device=qkv.device)
+        N.check(_L().sbgm_mha_core_dropout_fwd(qkv.data_ptr(), out.data_ptr(), B, S, Cc, heads, float(p), int(seed), 0, _st()))
+        ctx.save_for_backward(qkv)
+        ctx.dims = (B, S, Cc, heads, float(p), int(seed))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (qkv,) = ctx.saved_tensors
+        B, S, Cc, heads, p, seed = ctx.dims
+        dout = dout.contiguous()
+        dqkv, zeroed = _grad_zeros(qkv.numel(), qkv.device)
+        dqkv = dqkv.view(qkv.shape)
+        with _prezeroed(zeroed):
+            N.check(_L().sbgm_mha_core_dropout_bwd(qkv.data_ptr(), dout.data_ptr(), dqkv.data_ptr(), B, S, Cc, heads, p, seed, 0, _st()))
+        return dqkv, None, None, None, None, None, None
+
+
 class UpsampleFn(torch.autograd.Function):
     """nn.Upsample(scale_factor=scale, bilinear, align_corners=False) over NHWC; scale 2 (every block of the Decoder) has its own kernels"""
     @staticmethod
@@ -1079,14 +1102,21 @@ def _bn_eval(x, bn, res, tb_after, relu, rslot=None):
 
 def _attention(mod, x):                               # x: [B, H, W, C] -> same (reference score_unet.py:136-148)
     B, H, W, Cc = x.shape
-    if getattr(mod, "dropout", 0.0) > 0 and mod.training:
-        raise NotImplementedError("train-mode attention dropout (p > 0) is not implemented natively")
+    drop = float(getattr(mod, "dropout", 0.0)) if mod.training else 0.0
+    if drop > 0 and x.is_cuda and torch.cuda.is_current_stream_capturing():
+        # the mask's seed is a by-value kernel argument: a captured step would replay ONE mask for ever
+        raise RuntimeError("train-mode attention dropout draws a fresh seed per call and cannot be captured into a hipGraph: "
+                           "set training.use_hip_graph: false (auto does this by itself)")
     tok = x.reshape(B * H * W, Cc)
     grad = torch.is_grad_enabled() and tok.requires_grad
     s1 = _slot(2) if grad else None                          # tok feeds ln1 and the residual of out_proj
     n1 = LayerNormFn.apply(tok, mod.ln1.weight, mod.ln1.bias, mod.ln1.eps, s1)
     qkv = linear(n1, mod.mha.in_proj_weight, mod.mha.in_proj_bias)
-    att = MHACoreFn.apply(qkv, B, H * W, Cc, mod.n_heads)
+    if drop > 0:
+        from .score_sampling import _fresh_seed          # torch's CPU generator: torch.manual_seed makes the masks repeatable
+        att = MHACoreDropoutFn.apply(qkv, B, H * W, Cc, mod.n_heads, drop, _fresh_seed())
+    else:
+        att = MHACoreFn.apply(qkv, B, H * W, Cc, mod.n_heads)
     h = linear(att, mod.mha.out_proj.weight, mod.mha.out_proj.bias, res=tok, rslot=s1)
     s2 = _slot(2) if grad else None                          # h feeds ln2 and the residual of ff[2]
     n2 = LayerNormFn.apply(h, mod.ln2.weight, mod.ln2.bias, mod.ln2.eps, s2)

@@ -222,7 +222,8 @@ class TrainingPipeline_general:
         on_gpu = torch.device(self.device).type == "cuda"
         if auto:
             use_graph = (on_gpu and not getattr(self, "_graph_failed", False) and train_graph._sync_world() is None
-                         and not getattr(self.model, "debug_pre_sigma_div", False))
+                         and not getattr(self.model, "debug_pre_sigma_div", False)
+                         and not any(getattr(m, "dropout", 0.0) > 0 for m in self.model.modules() if type(m).__name__ == "ImageSelfAttention"))
         else:
             use_graph = (want if isinstance(want, bool) else str(want).strip().lower() in ("1", "true", "yes", "on")) and on_gpu
         if use_graph and train_graph._sync_world() is not None:

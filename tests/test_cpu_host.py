@@ -417,7 +417,7 @@ def test_graft_entry_build_hook():
 
 def test_attention_dropout_is_accepted_like_the_reference_signature():
     """ImageSelfAttention(..., dropout=p) (reference score_unet.py:118-127) constructs with p > 0 — the identity in eval mode, which the
-    sampling path uses; only a train-mode evaluation with p > 0 is refused (at call time)"""
+    sampling path uses; train mode runs the masked attention core on the autograd path (tests/test_gpu_backward.py)"""
     import sbgm_danra_amd as S
     a = S.ImageSelfAttention(64, 4, dropout=0.1)
     assert a.dropout == 0.1 and a.mha.dropout == 0.1

@@ -120,6 +120,61 @@ def test_layernorm_backward(M, Cc):
     assert maxrel(xd.grad.cpu(), xr.grad) < GT and maxrel(gd.grad.cpu(), gr.grad) < GT and maxrel(bd.grad.cpu(), br.grad) < GT
 
 
+@pytest.mark.parametrize("B,S,Cc,heads,p", [(2, 64, 64, 4, 0.25), (1, 50, 96, 2, 0.1), (3, 16, 256, 4, 0.5), (1, 256, 128, 4, 0.2), (2, 33, 32, 1, 0.0)])
+def test_attention_core_with_dropout(B, S, Cc, heads, p):
+    """train-mode nn.MultiheadAttention(dropout=p): out = (softmax(q k^T / sqrt(d)) o D) v with D = keep / (1 - p).  The kernels' mask is
+    read back through sbgm_mha_dropout_mask and the same expression is evaluated (forward and autograd) in torch on the CPU; the mask
+    itself must keep ~(1 - p) of the probabilities, differ between seeds and be the same for forward and backward."""
+    d, seed = Cc // heads, 1234567 + S
+    qkv = rnd(B, S, 3 * Cc, seed=S) * 0.7
+    go = rnd(B, S, Cc, seed=S + 1)
+    mask = torch.empty(B, heads, S, S, device="cuda")
+    N.check(T._L().sbgm_mha_dropout_mask(mask.data_ptr(), B, S, heads, p, seed, 0, N.stream()))
+    m = mask.cpu()
+    keep = float((m > 0).float().mean())
+    assert set(torch.unique(m).tolist()) <= {0.0, float(torch.tensor(1.0 / (1.0 - p), dtype=torch.float32))}
+    assert abs(keep - (1 - p)) < 4 * (p * (1 - p) / m.numel()) ** 0.5 + 1e-9
+    if p > 0:
+        other = torch.empty_like(mask)
+        N.check(T._L().sbgm_mha_dropout_mask(other.data_ptr(), B, S, heads, p, seed + 1, 0, N.stream()))
+        assert not torch.equal(other, mask)
+    qr = leaf(qkv)
+    q, k, v = [t.view(B, S, heads, d).transpose(1, 2) for t in qr.split(Cc, dim=-1)]
+    a = torch.softmax(q @ k.transpose(-1, -2) / d ** 0.5, dim=-1)
+    want = ((a * m) @ v).transpose(1, 2).reshape(B, S, Cc)
+    want.backward(go)
+    qd = leaf(qkv.view(B * S, 3 * Cc), True)
+    got = T.MHACoreDropoutFn.apply(qd, B, S, Cc, heads, p, seed)
+    got.backward(go.view(B * S, Cc).cuda())
+    assert maxrel(got.detach().cpu().view(B, S, Cc), want.detach()) < 1e-5
+    assert maxrel(qd.grad.cpu().view(B, S, 3 * Cc), qr.grad) < GT
+    if p == 0.0:                                               # no dropout: the same numbers as the production core
+        plain = T.MHACoreFn.apply(leaf(qkv.view(B * S, 3 * Cc), True), B, S, Cc, heads)
+        assert maxrel(plain.detach().cpu(), got.detach().cpu()) < 1e-5
+
+
+def test_attention_block_trains_with_dropout():
+    """ImageSelfAttention(dropout=p).train() through the autograd path: runs, is repeatable under torch.manual_seed, differs between
+    calls, and equals the eval-mode block when every probability is kept (p -> 0 limit: p = 0)"""
+    import sbgm_danra_amd as S
+    torch.manual_seed(3)
+    blk = S.ImageSelfAttention(64, 4, dropout=0.3).cuda()
+    x = (torch.randn(2, 8, 8, 64) * 0.5).cuda().requires_grad_(True)
+    blk.train()
+    torch.manual_seed(11); a = T._attention(blk, x)
+    torch.manual_seed(11); b = T._attention(blk, x)
+    c = T._attention(blk, x)
+    assert torch.equal(a, b) and not torch.equal(a, c) and torch.isfinite(a).all()
+    a.square().mean().backward()
+    assert x.grad is not None and torch.isfinite(x.grad).all() and all(p.grad is not None for p in blk.parameters())
+    blk.eval()
+    e = T._attention(blk, x)
+    blk0 = S.ImageSelfAttention(64, 4, dropout=0.0).cuda()
+    blk0.load_state_dict(blk.state_dict())
+    blk0.train()
+    assert maxrel(T._attention(blk0, x).detach().cpu(), e.detach().cpu()) < 1e-5
+
+
 def test_act_upsample_backward():
     M, Cc = 40, 256
     x, go = rnd(M, Cc) * 2 + 1, rnd(M, Cc, seed=3)

@@ -238,6 +238,15 @@ def test_hip_graph_is_the_default_and_falls_back_when_a_step_cannot_be_captured(
     assert int(model2.encoder.bn1.num_batches_tracked) == 2 and not torch.equal(before, model2.encoder.conv2.weight)
     c = pipe2.train_batches(dl, epochs=2, current_epoch=2, verbose=False)          # stays eager, keeps training
     assert np.isfinite(c) and int(model2.encoder.bn1.num_batches_tracked) == 4
+    # train-mode attention dropout draws a fresh seed per call: auto runs such a model eagerly from the start
+    torch.manual_seed(0)
+    model4, _, _ = get_model(cfg)
+    att = [m for m in model4.modules() if type(m).__name__ == "ImageSelfAttention"]
+    att[0].dropout = att[-1].dropout = 0.2
+    pipe4 = TrainingPipeline_general(model4, loss_fn, marginal_prob_std_fn, diffusion_coeff_fn, get_optimizer(cfg, model4),
+                                     torch.device("cuda"), None, cfg)
+    d = pipe4.train_batches(dl, epochs=1, current_epoch=1, verbose=False)
+    assert np.isfinite(d) and not getattr(pipe4, "_graphs", {}) and not getattr(pipe4, "_graph_failed", False)
     # an explicit `true` does not hide the problem
     cfg.training.use_hip_graph = True
     pipe3 = TrainingPipeline_general(model2, syncing_loss, marginal_prob_std_fn, diffusion_coeff_fn, get_optimizer(cfg, model2),
