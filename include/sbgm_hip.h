@@ -266,6 +266,10 @@ int sbgm_conv_wino2d_pack_weight(const float* w_oihw, float* packed, int Cout, i
  * 4x) followed by depth->space; its backward is space->depth followed by the 1x1 convolution's backward. */
 int sbgm_depth_to_space2(const float* x /* [B,H,W,4C] */, float* y /* [B,2H,2W,C] */, int B, int H, int W, int C, void* stream);
 int sbgm_space_to_depth2(const float* y /* [B,2H,2W,C] */, float* x /* [B,H,W,4C] */, int B, int H, int W, int C, void* stream);
+/* The same permutation for any stride s in 1..16 (ConvTranspose2d(k = s, stride = s): DecoderBlock(upsample_scale = s, use_resize_conv =
+ * False) called on its own): depth [B,H,W,s*s*C] with channels ordered (dy, dx, c) <-> space [B,s*H,s*W,C]. */
+int sbgm_depth_to_space(const float* x, float* y, int B, int H, int W, int C, int s, void* stream);
+int sbgm_space_to_depth(const float* y, float* x, int B, int H, int W, int C, int s, void* stream);
 int sbgm_tconv_weight_to_oihw(const float* w /* [Cin,Cout,2,2] */, float* oihw /* [4*Cout,Cin,1,1] */, int Cin, int Cout,
                               void* stream);
 /* nn.Upsample(scale_factor=2, mode="bilinear", align_corners=False).  score_unet.py:467 */

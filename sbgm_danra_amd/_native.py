@@ -83,6 +83,8 @@ SIGNATURES = {
     "sbgm_assemble_conditions": (_i, [C.POINTER(AssembleArgs), _vp]),
     "sbgm_depth_to_space2": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "sbgm_space_to_depth2": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
+    "sbgm_depth_to_space": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    "sbgm_space_to_depth": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "sbgm_tconv_weight_to_oihw": (_i, [_vp, _vp, _i, _i, _vp]),
     "sbgm_extract_tiles": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
     "sbgm_stitch_tiles": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),

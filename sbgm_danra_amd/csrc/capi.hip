@@ -265,6 +265,12 @@ int sbgm_depth_to_space2(const float* x, float* y, int B, int H, int W, int C, v
 int sbgm_space_to_depth2(const float* y, float* x, int B, int H, int W, int C, void* stream) {
     return sbgm_launch_depth_space2(y, x, B, H, W, C, 0, ST);
 }
+int sbgm_depth_to_space(const float* x, float* y, int B, int H, int W, int C, int s, void* stream) {
+    return sbgm_launch_depth_space(x, y, B, H, W, C, s, 1, ST);
+}
+int sbgm_space_to_depth(const float* y, float* x, int B, int H, int W, int C, int s, void* stream) {
+    return sbgm_launch_depth_space(y, x, B, H, W, C, s, 0, ST);
+}
 int sbgm_tconv_weight_to_oihw(const float* w, float* oihw, int Cin, int Cout, void* stream) {
     return sbgm_launch_tconv_weight(w, oihw, Cin, Cout, ST);
 }

@@ -103,6 +103,7 @@ int sbgm_launch_upsample2x(const float* x, float* y, int B, int H, int W, int C,
 int sbgm_launch_upsample_bilinear(const float* x, float* y, int B, int H, int W, int C, int scale, int backward, hipStream_t st);
 // [B][H][W][4C] (phase-major channels) <-> [B][2H][2W][C]; to_space = 1: depth -> space
 int sbgm_launch_depth_space2(const float* in, float* out, int B, int H, int W, int C, int to_space, hipStream_t st);
+int sbgm_launch_depth_space(const float* in, float* out, int B, int H, int W, int C, int s, int to_space, hipStream_t st);   // any stride s
 int sbgm_launch_tconv_weight(const float* w_cin_cout_2_2, float* oihw_4cout_cin, int Cin, int Cout, hipStream_t st);
 int sbgm_launch_act(float* x, size_t n, int act, hipStream_t st);
 int sbgm_launch_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var, float eps,

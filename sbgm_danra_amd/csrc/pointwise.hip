@@ -451,7 +451,31 @@ __global__ void tconv_weight_kernel(const float* __restrict__ w, float* __restri
         o[i] = w[((size_t)ci * Cout + co) * 4 + ph];
     }
 }
+// the same permutation for any stride s (ConvTranspose2d(k = s, stride = s) of a DecoderBlock(upsample_scale = s) called on its own):
+// depth [B][H][W][s*s*C] with channels ordered (dy, dx, c)  <->  space [B][sH][sW][C]
+__global__ __launch_bounds__(256) void depth_space_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H, int W, int C,
+                                                          int s, int to_space, size_t total4) {
+    const int c4n = C >> 2;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (size_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % c4n);
+        size_t r = i / c4n;
+        const int X = (int)(r % ((size_t)s * W)); r /= (size_t)s * W;
+        const int Y = (int)(r % ((size_t)s * H));
+        const int b = (int)(r / ((size_t)s * H));
+        const size_t d = ((((size_t)b * H + Y / s) * W + X / s) * (s * s) + ((Y % s) * s + X % s)) * c4n + c4;
+        if (to_space) reinterpret_cast<f32x4*>(out)[i] = reinterpret_cast<const f32x4*>(in)[d];
+        else reinterpret_cast<f32x4*>(out)[d] = reinterpret_cast<const f32x4*>(in)[i];
+    }
+}
 }  // namespace
+
+int sbgm_launch_depth_space(const float* in, float* out, int B, int H, int W, int C, int s, int to_space, hipStream_t st) {
+    SBGM_CHECK(C % 4 == 0 && s >= 1 && s <= 16, "depth<->space: C=%d must be a multiple of 4, stride %d in 1..16", C, s);
+    const size_t total4 = (size_t)B * s * s * H * W * (C / 4);
+    hipLaunchKernelGGL(depth_space_kernel, dim3(stream_blocks(total4 * 4)), dim3(256), 0, st, in, out, B, H, W, C, s, to_space, total4);
+    SBGM_LAUNCH_CHECK();
+    return 0;
+}
 
 int sbgm_launch_depth_space2(const float* in, float* out, int B, int H, int W, int C, int to_space, hipStream_t st) {
     SBGM_CHECK(C % 4 == 0, "depth<->space: C=%d must be a multiple of 4", C);

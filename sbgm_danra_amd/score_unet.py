@@ -156,8 +156,6 @@ class DecoderBlock(_NativeOnly):
         self.use_resize_conv, self.norm_kind, self.gn_groups = use_resize_conv, norm, gn_groups
         if int(upsample_scale) != upsample_scale or not 1 <= upsample_scale <= 16:
             raise NotImplementedError("upsample_scale must be an integer in 1..16")
-        if upsample_scale != 2 and not use_resize_conv:
-            raise NotImplementedError("the ConvTranspose2d ablation path is implemented for the reference's x2 upsampling only")
         if use_resize_conv:
             self.upsample = nn.Upsample(scale_factor=upsample_scale, mode="bilinear", align_corners=False)
             self.conv_up = nn.Conv2d(input_channels, input_channels, kernel_size=3, padding=1, bias=True)

@@ -858,31 +858,39 @@ class UpsampleFn(torch.autograd.Function):
 
 
 class DepthToSpaceFn(torch.autograd.Function):
-    """[B,H,W,4C] (phase-major channels) -> [B,2H,2W,C]; backward is the inverse permutation"""
+    """[B,H,W,s*s*C] (phase-major channels) -> [B,sH,sW,C]; backward is the inverse permutation (s = 2: the Decoder's own kernels)"""
     @staticmethod
-    def forward(ctx, x):
-        B, H, W, C4 = x.shape
-        y = torch.empty(B, 2 * H, 2 * W, C4 // 4, device=x.device)
-        N.check(_L().sbgm_depth_to_space2(x.data_ptr(), y.data_ptr(), B, H, W, C4 // 4, _st()))
-        ctx.dims = (B, H, W, C4)
+    def forward(ctx, x, s=2):
+        B, H, W, Cd = x.shape
+        Cc = Cd // (s * s)
+        y = torch.empty(B, s * H, s * W, Cc, device=x.device)
+        if s == 2:
+            N.check(_L().sbgm_depth_to_space2(x.data_ptr(), y.data_ptr(), B, H, W, Cc, _st()))
+        else:
+            N.check(_L().sbgm_depth_to_space(x.data_ptr(), y.data_ptr(), B, H, W, Cc, s, _st()))
+        ctx.dims = (B, H, W, Cd, s)
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        B, H, W, C4 = ctx.dims
+        B, H, W, Cd, s = ctx.dims
         dy = dy.contiguous()
-        dx = torch.empty(B, H, W, C4, device=dy.device)
-        N.check(_L().sbgm_space_to_depth2(dy.data_ptr(), dx.data_ptr(), B, H, W, C4 // 4, _st()))
-        return dx
+        dx = torch.empty(B, H, W, Cd, device=dy.device)
+        if s == 2:
+            N.check(_L().sbgm_space_to_depth2(dy.data_ptr(), dx.data_ptr(), B, H, W, Cd // 4, _st()))
+        else:
+            N.check(_L().sbgm_space_to_depth(dy.data_ptr(), dx.data_ptr(), B, H, W, Cd // (s * s), s, _st()))
+        return dx, None
 
 
 def conv_transpose2x(x, mod):
-    """nn.ConvTranspose2d(C, C, 2, stride=2) (reference score_unet.py:472-475, :589) = 1x1 conv to 4C phase-major channels
-    + depth->space.  The weight/bias rearrangement is plain autograd-tracked tensor indexing on the parameters."""
+    """nn.ConvTranspose2d(C, C, s, stride=s) (reference score_unet.py:472-475, :589; s = 2 in the Decoder) = 1x1 conv to s*s*C phase-major
+    channels + depth->space.  The weight/bias rearrangement is plain autograd-tracked tensor indexing on the parameters."""
     ci, co = mod.weight.shape[0], mod.weight.shape[1]
-    w1 = mod.weight.permute(2, 3, 1, 0).reshape(4 * co, ci, 1, 1).contiguous()       # [(dy,dx,co), ci]
-    b4 = None if mod.bias is None else mod.bias.repeat(4)
-    return DepthToSpaceFn.apply(ConvFn.apply(x, w1, b4, None, None, 1, 0))
+    s = int(mod.weight.shape[2])
+    w1 = mod.weight.permute(2, 3, 1, 0).reshape(s * s * co, ci, 1, 1).contiguous()       # [(dy,dx,co), ci]
+    bs = None if mod.bias is None else mod.bias.repeat(s * s)
+    return DepthToSpaceFn.apply(ConvFn.apply(x, w1, bs, None, None, 1, 0), s)
 
 
 class ActFn(torch.autograd.Function):

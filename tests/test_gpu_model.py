@@ -438,15 +438,16 @@ def test_standalone_submodule_calls_match_the_oracle(mode):
                 assert maxrel(gn.cpu(), go) < 1e-4, i
 
 
-@pytest.mark.parametrize("scale,with_skip", [(4, True), (1, False), (3, True)])
-def test_decoder_block_with_another_upsample_scale(scale, with_skip):
+@pytest.mark.parametrize("scale,with_skip,resize", [(4, True, True), (1, False, True), (3, True, True), (4, True, False), (3, False, False)])
+def test_decoder_block_with_another_upsample_scale(scale, with_skip, resize):
     """DecoderBlock(upsample_scale=s) (reference score_unet.py:420, :467: nn.Upsample(scale_factor=s, bilinear)) called on its own,
     forward and gradients against the oracle's block with the same weights.  The whole-network engine refuses such a block."""
     import sbgm_danra_amd as S
     from oracle import torch_ref as O
     torch.manual_seed(scale)
-    bo = O.DecoderBlock(128, 64, 128, upsample_scale=scale, activation=nn.SiLU, compute_attn=False, norm="group", gn_groups=8)
-    bn = S.DecoderBlock(128, 64, 128, upsample_scale=scale, activation=nn.SiLU, compute_attn=False, norm="group", gn_groups=8).cuda()
+    kw = dict(upsample_scale=scale, activation=nn.SiLU, compute_attn=False, norm="group", gn_groups=8, use_resize_conv=resize)
+    bo = O.DecoderBlock(128, 64, 128, **kw)
+    bn = S.DecoderBlock(128, 64, 128, **kw).cuda()
     bn.load_state_dict(bo.state_dict())
     g = torch.Generator().manual_seed(7)
     B, h = 3, 6
@@ -461,11 +462,11 @@ def test_decoder_block_with_another_upsample_scale(scale, with_skip):
     yn.square().mean().backward()
     assert maxrel(xn.grad.cpu(), xo.grad) < 1e-4
     po, pn = dict(bo.named_parameters()), dict(bn.named_parameters())
-    for k in ("conv_up.weight", "conv.weight", "norm1.weight", "time_projection_layer.1.weight"):
+    for k in ("conv_up.weight" if resize else "transpose.weight", "conv.weight", "norm1.weight", "time_projection_layer.1.weight"):
         assert maxrel(pn[k].grad.cpu(), po[k].grad) < 1e-4, k
     with pytest.raises(NotImplementedError):
-        S.DecoderBlock(64, 32, 128, upsample_scale=4, use_resize_conv=False)
-    if scale == 4:
+        S.DecoderBlock(64, 32, 128, upsample_scale=0)
+    if scale == 4 and resize:
         _, net, _ = build_pair(1)
         net.decoder.residual_layers[3] = S.DecoderBlock(64, 64, 256, upsample_scale=4, activation=nn.SiLU, compute_attn=False,
                                                         norm="group", gn_groups=8).cuda()
