@@ -155,14 +155,16 @@ def cpu_baseline(batch, hw, budget_s=20.0, sampler="em", n_cond=1, max_steps=50)
                       f"({dt:.1f} s, PyTorch-CPU {torch.__version__}, {model}; threads = {how})"}
 
 
-def sampling_secondary(dev, B, HW, sampler_key, steps, warmup, n_cond=1):
+def sampling_secondary(dev, B, HW, sampler_key, steps, warmup, n_cond=1, tune=True):
     """another BASELINE sampling configuration beside the headline (C4: 256x256, batch 16, predictor-corrector; C1: 64x64, one
-    sample, no condition): same timing rules as the headline, its own autotune and its own roofline block"""
+    sample, no condition): same timing rules as the headline, its own autotune and its own roofline block.  tune=False: the engine's
+    static kernel choice, i.e. what a caller of the public samplers gets without ever calling ScoreNet.autotune"""
     import sbgm_danra_amd as S
     net = build_model(dev, n_cond=n_cond)
     g = torch.Generator().manual_seed(42)
     cond = torch.randn(B, n_cond, HW, HW, generator=g).to(dev) if n_cond else None
-    net.autotune(B, HW, HW, cond_channels=(0, 0, n_cond))
+    if tune:
+        net.autotune(B, HW, HW, cond_channels=(0, 0, n_cond))
     sampler = S.Euler_Maruyama_sampler if sampler_key == "em" else S.pc_sampler
     evals = 1 if sampler_key == "em" else 2
     kw = dict(batch_size=B, device=dev, img_size=HW, cond_img=cond, use_graph=True, seed=1234)
@@ -178,11 +180,11 @@ def sampling_secondary(dev, B, HW, sampler_key, steps, warmup, n_cond=1):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     assert torch.isfinite(out).all()
-    roof = conv_roofline(net, cond, B, HW, sampler_key, dt / (steps * evals) * 1e3, dev) if n_cond else None
+    roof = conv_roofline(net, cond, B, HW, sampler_key, dt / (steps * evals) * 1e3, dev) if n_cond and tune else None
     return {"value": B * steps / dt, "unit": "denoising steps/s", "ms_per_step": dt / steps * 1e3, "steps": steps, "warmup": warmup,
             "network_evals_per_s": B * steps * evals / dt,
             "workload": f"{HW}x{HW}, C_in={1 + n_cond}, batch {B}, {'Euler-Maruyama' if sampler_key == 'em' else 'predictor-corrector'} "
-                        f"({evals} network eval/step), hipGraph on", "roofline": roof}
+                        f"({evals} network eval/step), hipGraph on" + ("" if tune else ", NO autotune (static kernel choice)"), "roofline": roof}
 
 
 def domain_secondary(dev, steps, warmup):
@@ -688,7 +690,8 @@ def main():
         for name, fn in (("train_c3", lambda: train_secondary(dev)),
                          ("c4_pc", lambda: sampling_secondary(dev, 16, 256, "pc", 10, 3)),
                          ("c5_domain", lambda: domain_secondary(dev, 6, 2)),
-                         ("c1_em", lambda: sampling_secondary(dev, 1, 64, "em", 50, 5, n_cond=0))):
+                         ("c1_em", lambda: sampling_secondary(dev, 1, 64, "em", 50, 5, n_cond=0)),
+                         ("c2_untuned", lambda: sampling_secondary(dev, 32, 128, "em", a.steps, a.warmup, tune=False))):
             try:
                 secondary[name] = fn()
             except Exception as e:
