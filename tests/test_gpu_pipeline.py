@@ -353,6 +353,45 @@ def test_graph_steps_with_two_batch_shapes_use_their_own_gradients(cfg_path):
     assert len(pipe._graphs) == 2
 
 
+def test_cli_training_on_two_ranks_keeps_the_replicas_identical(cfg_path, tmp_path):
+    """`python -m torch.distributed.run --nproc-per-node 2 -m sbgm.cli.main_app --mode train` rehearsed on this box's one GPU over gloo:
+    the pipeline's default (captured step, gradient all-reduce on the arena after each replay, 1/world folded into Adam, rank-sharded
+    loader, rank-distinct noise) must leave both replicas with bit-identical weights."""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    code = ("import sys, torch; sys.path.insert(0, %r); from sbgm.cli import main_app; from sbgm.utils import load_config; import os\n"
+            "cfg = load_config(%r)\n"
+            "from sbgm_danra_amd.training_main import train_main\n"
+            "cfg.training.epochs = 1; cfg.monitoring.extreme_prcp.enabled = False\n"
+            "import sbgm_danra_amd.training as TR\n"
+            "orig = TR.TrainingPipeline_general.train_batches\n"
+            "def spy(self, *a, **k):\n"
+            "    r = orig(self, *a, **k)\n"
+            "    torch.save({'sd': {k_: v.cpu() for k_, v in self.model.state_dict().items()}, 'graphs': len(getattr(self, '_graphs', {}))},\n"
+            "               os.path.join(%r, 'rank%%s.pt' %% os.environ.get('RANK', '0')))\n"
+            "    return r\n"
+            "TR.TrainingPipeline_general.train_batches = spy\n"
+            "train_main(cfg)\n") % (ROOT, cfg_path, str(tmp_path))
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    base["SBGM_DIST_BACKEND"] = "gloo"
+    procs = [subprocess.Popen([sys.executable, "-c", code], env=dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2",
+                                                                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-2000:] for o in outs)
+    a, b = (torch.load(os.path.join(str(tmp_path), f"rank{r}.pt"), weights_only=True) for r in range(2))
+    assert a["graphs"] >= 1 and b["graphs"] >= 1                      # the captured step was the default on both ranks
+    for k in a["sd"]:
+        if "running_" in k or "num_batches" in k:                      # per-replica BatchNorm statistics (DistributedDataParallel's default)
+            continue
+        assert torch.equal(a["sd"][k], b["sd"][k]), k
+    assert all(torch.isfinite(v).all() for v in a["sd"].values() if v.dtype.is_floating_point)
+
+
 @pytest.mark.parametrize("mode,extra", [("sample", ["--batch", "2", "--size", "64"]), ("train", ["--batch", "2", "--size", "64"]),
                                         ("train", ["--batch", "2", "--size", "64", "--sync-bn"]), ("domain", [])])
 def test_bench_multi_rank_rehearsal_on_one_gpu(mode, extra):
