@@ -95,13 +95,19 @@ class SampleGenerator:
             x, seasons, cond, lsm, topo = [None if t is None else t[:1] for t in (x, seasons, cond, lsm, topo)]
         return x, seasons, cond, lsm, topo
 
+    @staticmethod
+    def _rank_suffix():
+        """with several ranks every rank owns whole batches and writes its own files (two ranks writing one path would race)"""
+        rank, world = parallel.world()
+        return f"_rank{rank}" if world > 1 else ""
+
     def generate_multiple(self):
         x, seasons, cond, lsm, topo = self._batch()
-        return self._generate(x, seasons, cond, lsm, topo, f"multi_n_{x.shape[0]}")
+        return self._generate(x, seasons, cond, lsm, topo, f"multi_n_{x.shape[0]}" + self._rank_suffix())
 
     def generate_single(self):
         x, seasons, cond, lsm, topo = self._batch(first_only=True)
-        return self._generate(x, seasons, cond, lsm, topo, "single")
+        return self._generate(x, seasons, cond, lsm, topo, "single" + self._rank_suffix())
 
     def generate_repeated(self):
         """cfg.evaluation.n_repeats samples from ONE conditioning sample, drawn as one batch (independent noise per

@@ -21,6 +21,10 @@ def generation_main(cfg, dataloader=None, back_transforms=None):
     gen_dir = os.path.join(cfg["paths"]["sample_dir"], "generation", get_model_string(cfg))
     log = setup_logger(os.path.join(gen_dir, "logs"), name="gen_log")
     rank, world, local = parallel.init_distributed()
+    if world > 1:      # one process per GPU: every rank generates from its own conditioning batch with its own noise and writes *_rank<r> files
+        torch.manual_seed(seed + rank)
+        torch.cuda.manual_seed(seed + rank)
+        np.random.seed(seed + rank)
     dev = cfg["training"]["device"]
     device = torch.device("cuda", local) if dev == "cuda" and torch.cuda.is_available() else torch.device("cpu")
     model, ckpt_dir, ckpt_name = get_model(cfg)
@@ -32,7 +36,7 @@ def generation_main(cfg, dataloader=None, back_transforms=None):
         # reference generation_main.py:93-108: inverse transforms from the saved global statistics (device-side classes)
         from ..training import TrainingPipeline_general
         back_transforms = TrainingPipeline_general._build_back_transforms(cfg)
-    gen = SampleGenerator(cfg, model, dataloader if dataloader is not None else get_gen_dataloader(cfg), back_transforms, device)
+    gen = SampleGenerator(cfg, model, dataloader if dataloader is not None else get_gen_dataloader(cfg, shard=(rank, world)), back_transforms, device)
     out = {}
     for kind in cfg["evaluation"]["gen_type"]:
         if kind not in ("multiple", "single", "repeated"):

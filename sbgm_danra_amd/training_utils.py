@@ -87,9 +87,11 @@ def get_dataloader(cfg, shard=None):
             synthetic_loader(cfg, bs, n_items=2 * bs, seed=2), synthetic_loader(cfg, n_gen, n_items=n_gen, seed=3))
 
 
-def get_gen_dataloader(cfg):
+def get_gen_dataloader(cfg, shard=None):
+    """`shard=(rank, world)`: every rank draws its OWN evaluation batch (independent units, no collective: SURVEY.md 8e)"""
     bs = int(cfg["evaluation"]["batch_size"])
-    return synthetic_loader(cfg, bs, n_items=bs, seed=4)
+    world = shard[1] if shard is not None else 1
+    return synthetic_loader(cfg, bs, n_items=bs * world, seed=4, shard=shard if world > 1 else None)
 
 
 def setup_logger(log_dir, name="train_log"):

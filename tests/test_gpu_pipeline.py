@@ -353,6 +353,43 @@ def test_graph_steps_with_two_batch_shapes_use_their_own_gradients(cfg_path):
     assert len(pipe._graphs) == 2
 
 
+def test_cli_generation_on_two_ranks_writes_rank_owned_batches(cfg_path):
+    """`--mode generate` under two ranks (gloo rehearsal on one GPU): every rank samples its own conditioning batch with its own noise and
+    writes *_rank<r> files — no two ranks write one path, the two batches differ, the repeats are split between the ranks"""
+    import socket
+    import subprocess
+    import sys
+    from oracle import torch_ref as O
+    from sbgm.utils import get_model_string, load_config
+    cfg = load_config(cfg_path)
+    ora = O.build_scorenet(6, num_classes=4)
+    ckpt_dir = os.path.join(cfg.paths.path_save, cfg.paths.checkpoint_dir)
+    os.makedirs(ckpt_dir, exist_ok=True)
+    torch.save({"network_params": O.synth_state_dict(ora), "optimizer_params": {}}, os.path.join(ckpt_dir, get_model_string(cfg) + ".pth.tar"))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    code = "import sys; sys.path.insert(0, %r); from sbgm.cli import main_app; main_app.main(['--config_path', %r, '--mode', 'generate'])" % (ROOT, cfg_path)
+    base = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    base["SBGM_DIST_BACKEND"] = "gloo"
+    procs = [subprocess.Popen([sys.executable, "-c", code], env=dict(base, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2",
+                                                                      MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
+    outs = [p.communicate(timeout=900)[0] for p in procs]
+    assert all(p.returncode == 0 for p in procs), "\n".join(o[-2000:] for o in outs)
+    out = os.path.join(cfg.paths.sample_dir, "generation", get_model_string(cfg), "generated_samples")
+    files = set(os.listdir(out))
+    want = {f"gen_samples_multi_n_3_rank{r}.npz" for r in range(2)} | {f"gen_samples_single_rank{r}.npz" for r in range(2)} \
+        | {f"gen_samples_repeated_n_2_rank{r}.npz" for r in range(2)}
+    assert want <= files and "gen_samples_multi_n_3.npz" not in files, sorted(files)
+    a, b = (np.load(os.path.join(out, f"gen_samples_multi_n_3_rank{r}.npz"))["arr_0"] for r in range(2))
+    assert a.shape == b.shape == (3, 64, 64) and np.isfinite(a).all() and np.isfinite(b).all() and not np.array_equal(a, b)
+    ea, eb = (np.load(os.path.join(out, f"eval_samples_multi_n_3_rank{r}.npz"))["arr_0"] for r in range(2))
+    assert not np.array_equal(ea, eb)                                  # different conditioning batches
+    reps = [np.load(os.path.join(out, f"gen_samples_repeated_n_2_rank{r}.npz"))["arr_0"] for r in range(2)]
+    assert sum(r_.shape[0] if r_.ndim == 3 else 1 for r_ in reps) == 2
+
+
 def test_cli_training_on_two_ranks_keeps_the_replicas_identical(cfg_path, tmp_path):
     """`python -m torch.distributed.run --nproc-per-node 2 -m sbgm.cli.main_app --mode train` rehearsed on this box's one GPU over gloo:
     the pipeline's default (captured step, gradient all-reduce on the arena after each replay, 1/world folded into Adam, rank-sharded
