@@ -128,11 +128,12 @@ class TrainingPipeline_general:
                 loss.backward()
                 return loss
             saved = {k: v.detach().clone() for k, v in self.model.state_dict().items()}      # warm-up must not train
+            entry_stream = torch.cuda.current_stream()
             try:
                 side = torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
-                    for _ in range(2):
+                    for _ in range(3):                       # tile tuning, then the weight-pack plan settles (one more than it needs)
                         self.optimizer.zero_grad(set_to_none=True)
                         fwd_bwd()
                 torch.cuda.current_stream().wait_stream(side)
@@ -142,6 +143,9 @@ class TrainingPipeline_general:
                 with torch.cuda.graph(graph):
                     loss = fwd_bwd()
             except Exception as e:                                                             # noqa: BLE001
+                # torch.cuda.graph.__exit__ ends the capture FIRST and restores the thread's stream after it: when ending an invalidated
+                # capture raises, the thread is left on the dead capture stream and every later launch fails.  Put it back.
+                torch.cuda.set_stream(entry_stream)
                 if not soft:
                     raise
                 # `auto` mode: something in this step cannot be captured (a host synchronisation inside a user-supplied loss / model
