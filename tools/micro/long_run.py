@@ -1,11 +1,10 @@
 """C2 at its full length: 1000 Euler-Maruyama steps at B=32, 128x128, graph replay against eager launches."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests"))
 import torch
 import sbgm_danra_amd as S
-from util_models import build_pair
-_, net, _ = build_pair(1)
+from bench import build_model        # the bench's model: reference training initialisation, no oracle involved
+net = build_model(torch.device('cuda'))
 net.eval()
 g = torch.Generator().manual_seed(2)
 c = torch.randn(32, 1, 128, 128, generator=g).cuda()

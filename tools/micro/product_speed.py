@@ -2,10 +2,24 @@
 C2's shape, then a full-featured model (4 low-res conditions + lsm + topo + 4 season classes)."""
 import sys, os, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT)
 import torch
 import sbgm_danra_amd as S
-from util_models import build_pair
+import torch.nn as nn
+
+
+def build(n_in, classes=None):
+    """a model with the reference's training initialisation (as bench.build_model; no oracle involved)"""
+    enc = S.Encoder(n_in, 256, block_layers=[2, 2, 2, 2], n_heads=4, num_classes=classes)
+    dec = S.Decoder(512, 1, 256, n_heads=4, norm="group", gn_groups=8, activation=nn.SiLU)
+    net = S.ScoreNet(S.marginal_prob_std_fn, enc, dec, device=torch.device("cuda"), debug_pre_sigma_div=False)
+    with torch.no_grad():
+        for m in net.modules():
+            if isinstance(m, (nn.Conv2d, nn.ConvTranspose2d)):
+                nn.init.xavier_uniform_(m.weight)
+                if m.bias is not None:
+                    m.bias.fill_(0.01)
+    return net.eval()
 
 
 def run(label, net, fn, evals_per_step, steps, **kw):
@@ -17,12 +31,11 @@ def run(label, net, fn, evals_per_step, steps, **kw):
 
 
 g = torch.Generator().manual_seed(1)
-_, net, _ = build_pair(1)
-net.eval()
+net = build(1)
 c = torch.randn(32, 1, 128, 128, generator=g).cuda()
 run("C2 em", net, S.Euler_Maruyama_sampler, 1, 500, batch_size=32, img_size=128, cond_img=c, seed=1)
 run("C2 pc", net, S.pc_sampler, 2, 250, batch_size=32, img_size=128, cond_img=c, seed=1)
-_, full, _ = build_pair(8, num_classes=4)
+full = build(8, 4)
 if True:
     full.eval()
     c4 = torch.randn(32, 4, 128, 128, generator=g).cuda()
