@@ -4,8 +4,9 @@
 (b) the reference's training initialisation (torch default init + xavier_uniform on Conv2d, bias 0.01, seed 42; reference
     training.py:188-201): every gradient, native vs fp32 oracle and vs float64."""
 import copy, json, os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+_TESTS = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))          # .../tests (this probe is test infrastructure: it uses the oracle)
+sys.path.insert(0, os.path.dirname(_TESTS))
+sys.path.insert(0, _TESTS)
 import torch, torch.nn as nn
 from util_models import build_pair, maxrel
 import sbgm_danra_amd as S

@@ -122,7 +122,7 @@ def test_config3_training_step_128x128_batch8_all_gradients(init):
     """C3 per-GPU step (128x128, C_in = 5, B = 8, train-mode BatchNorm): loss and EVERY parameter gradient against a float64
     evaluation of the oracle, for the hash-generated test weights and for the reference's training initialisation.
 
-    What the data says (tools/c3_grad_probe.py).  Compared naively, ~40-60 encoder gradients differ from float64 by
+    What the data says (tests/probes/c3_grad_probe.py).  Compared naively, ~40-60 encoder gradients differ from float64 by
     1e-3..3e-2 — for the native kernels AND for the reference's own fp32 CPU arithmetic alike, with either initialisation, with no
     low-variance or dead BatchNorm channel anywhere (min batch variance 0.13).  The cause is discrete: the 17 ReLUs of the encoder
     see ~2.6 M pre-activations, a handful of which lie within rounding distance of zero, and an arithmetic that lands on the other
