@@ -129,33 +129,39 @@ class TrainingPipeline_general:
                 return loss
             saved = {k: v.detach().clone() for k, v in self.model.state_dict().items()}      # warm-up must not train
             entry_stream = torch.cuda.current_stream()
-            try:
-                side = torch.cuda.Stream()
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    for _ in range(3):                       # tile tuning, then the weight-pack plan settles (one more than it needs)
-                        self.optimizer.zero_grad(set_to_none=True)
-                        fwd_bwd()
-                torch.cuda.current_stream().wait_stream(side)
-                self.model.load_state_dict(saved)                                              # BatchNorm running statistics back
-                graph = torch.cuda.CUDAGraph()
-                self.optimizer.zero_grad(set_to_none=True)
-                with torch.cuda.graph(graph):
-                    loss = fwd_bwd()
-            except Exception as e:                                                             # noqa: BLE001
-                # torch.cuda.graph.__exit__ ends the capture FIRST and restores the thread's stream after it: when ending an invalidated
-                # capture raises, the thread is left on the dead capture stream and every later launch fails.  Put it back.
-                torch.cuda.set_stream(entry_stream)
-                if not soft:
-                    raise
-                # `auto` mode: something in this step cannot be captured (a host synchronisation inside a user-supplied loss / model
-                # hook, ...).  Put the model back as it was and let the caller run this and every later step eagerly.
-                torch.cuda.synchronize()
-                self.model.load_state_dict(saved)
-                self.optimizer.zero_grad(set_to_none=True)
-                self._graph_failed = True
-                logger.warning(f"training.use_hip_graph=auto: the step could not be captured ({type(e).__name__}: {e}); continuing with eager steps")
-                return None
+            graph = loss = None
+            for attempt in range(2 if soft else 1):          # auto mode: one retry (a capture can be invalidated by something transient)
+                try:
+                    side = torch.cuda.Stream()
+                    side.wait_stream(torch.cuda.current_stream())
+                    with torch.cuda.stream(side):
+                        for _ in range(3 if attempt == 0 else 1):   # tile tuning, then the weight-pack plan settles (one more than it needs)
+                            self.optimizer.zero_grad(set_to_none=True)
+                            fwd_bwd()
+                    torch.cuda.current_stream().wait_stream(side)
+                    self.model.load_state_dict(saved)                                          # BatchNorm running statistics back
+                    graph = torch.cuda.CUDAGraph()
+                    self.optimizer.zero_grad(set_to_none=True)
+                    with torch.cuda.graph(graph):
+                        loss = fwd_bwd()
+                    break
+                except Exception as e:                                                         # noqa: BLE001
+                    # torch.cuda.graph.__exit__ ends the capture FIRST and restores the thread's stream after it: when ending an
+                    # invalidated capture raises, the thread is left on the dead capture stream and every later launch fails.  Put it back.
+                    torch.cuda.set_stream(entry_stream)
+                    if not soft:
+                        raise
+                    # `auto` mode: something in this step cannot be captured (a host synchronisation inside a user-supplied loss /
+                    # model hook, ...).  Put the model back as it was; after the second failure the caller runs eager steps from here on.
+                    torch.cuda.synchronize()
+                    self.model.load_state_dict(saved)
+                    self.optimizer.zero_grad(set_to_none=True)
+                    graph = loss = None
+                    if attempt == 1:
+                        self._graph_failed = True
+                        logger.warning(f"training.use_hip_graph=auto: the step could not be captured ({type(e).__name__}: {e}); "
+                                       f"continuing with eager steps")
+                        return None
             # each capture leaves ITS gradient tensors in .grad (graph-pool memory, or the model's arena): keep them with the
             # graph, so that replaying an older graph after a newer capture hands the optimizer the tensors that replay wrote
             params = [p for p in self.model.parameters() if p.grad is not None]
